@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference
+for the NB part):  python oracle/make_golden.py
+
+NB EMS  (tests/golden/nb_ref_<snr>dB.npz): outputs of the REFERENCE's own CPU
+  decoder (oracle/_ref/nb_ref, compiled from /root/reference/myNBLDPC/src/*.cpp)
+  for the first 16 frames of the seed-173 stream at Eb/N0 = 2, 3 and 5 dB:
+  channel samples rx, DecodeOutput, iter_number, return flag, fold hashes of
+  L_ch / final LLR / final c2v for every frame, and the full L_ch / LLR / c2v
+  arrays of a few frames.
+binary  (tests/golden/bldpc_*.npz): inputs y and outputs D of OUR restatement
+  (oracle/bldpc_oracle.c) whose D-hashes equal the values SURVEY.md 8c recorded
+  from a host emulation of the reference kernels; the fixture stores y so a
+  libm difference on another box cannot perturb decode parity.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as orc  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+FULL_FRAMES = {2.0: [0], 3.0: [0, 1, 4], 5.0: [0]}
+
+
+def parse_nb_dump(path):
+    b = open(path, "rb").read()
+    hdr = np.frombuffer(b[:32], np.int32)
+    N, M, q, dv, dc, maxit, nf, _ = (int(x) for x in hdr)
+    sigma, rate = np.frombuffer(b[32:40], np.float32)
+    off = 40
+    cw = np.frombuffer(b[off:off + 4 * N], np.int32).copy(); off += 4 * N
+    m = int(np.log2(q))
+    recs = []
+    for _fr in range(nf):
+        r = {}
+        r["rx"] = np.frombuffer(b[off:off + 4 * N * m], np.float32).copy(); off += 4 * N * m
+        r["Lch"] = np.frombuffer(b[off:off + 4 * N * (q - 1)], np.float32).reshape(N, q - 1).copy(); off += 4 * N * (q - 1)
+        r["out"] = np.frombuffer(b[off:off + 4 * N], np.int32).copy(); off += 4 * N
+        r["it"], r["ok"] = (int(x) for x in np.frombuffer(b[off:off + 8], np.int32)); off += 8
+        r["LLR"] = np.frombuffer(b[off:off + 4 * N * (q - 1)], np.float32).reshape(N, q - 1).copy(); off += 4 * N * (q - 1)
+        r["c2v"] = np.frombuffer(b[off:off + 4 * M * dc * (q - 1)], np.float32).reshape(M, dc, q - 1).copy(); off += 4 * M * dc * (q - 1)
+        recs.append(r)
+    assert off == len(b)
+    return dict(N=N, M=M, q=q, dv=dv, dc=dc, maxit=maxit, sigma=float(sigma), rate=float(rate), cw=cw, recs=recs)
+
+
+def make_nb():
+    ref = orc.ref_binary()
+    if ref is None:
+        print("oracle/_ref/nb_ref missing -> NB golden not regenerated")
+        return
+    for snr in (2.0, 3.0, 5.0):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "d.bin")
+            subprocess.check_call([ref, "dump", str(snr), "16", out], cwd=os.path.join(ROOT, "data", "nb"),
+                                  stdout=subprocess.DEVNULL)
+            d = parse_nb_dump(out)
+        recs = d["recs"]
+        full = FULL_FRAMES[snr]
+        np.savez_compressed(
+            os.path.join(GOLD, "nb_ref_%gdB.npz" % snr),
+            snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"],
+            rx=np.stack([r["rx"] for r in recs]), out=np.stack([r["out"] for r in recs]),
+            it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
+            Lch_hash=np.array([orc.fold_hash(r["Lch"]) for r in recs], np.uint32),
+            LLR_hash=np.array([orc.fold_hash(r["LLR"]) for r in recs], np.uint32),
+            c2v_hash=np.array([orc.fold_hash(r["c2v"]) for r in recs], np.uint32),
+            full_frames=np.array(full, np.int32),
+            full_Lch=np.stack([recs[i]["Lch"] for i in full]), full_LLR=np.stack([recs[i]["LLR"] for i in full]),
+            full_c2v=np.stack([recs[i]["c2v"] for i in full]))
+        print("NB %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+    np.savetxt(os.path.join(ROOT, "data", "nb", "codeword_bds_gf64.txt"), d["cw"][None, :], fmt="%d")
+
+
+# (file, J, L, Z, F, Es/N0 dB, literal table?, hash recorded in SURVEY.md 8c or None)
+BIN_CASES = [
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 3.0, False, 0x05A41534),
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 4.0, True, 0x90C5DF9B),
+    ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 16, -1.0, False, 0xC00D92C5),
+]
+
+
+def make_binary():
+    for name, J, L, Z, F, snr, literal, want in BIN_CASES:
+        code = orc.BinaryCode(os.path.join(ROOT, "data", "bldpc", name), J, L, Z, literal=literal)
+        seed = np.array([173, 173, 173], np.int32)
+        sigma = orc.bldpc_sigma(snr)
+        y = orc.bldpc_awgn(seed, sigma, code.N, F)
+        r = orc.bldpc_decode(code, y, F, 50, early_exit=1)
+        h = orc.fold_hash(r["D"][: code.N * F])
+        assert want is None or h == want, "%s %g dB: %08x != %08x" % (name, snr, h, want)
+        tag = "%s_%gdB_%s" % (name.split("_BlockH")[0], snr, "lit" if literal else "cor")
+        np.savez_compressed(os.path.join(GOLD, "bldpc_%s.npz" % tag), J=J, L=L, Z=Z, F=F, snr=np.float32(snr),
+                            sigma=np.float32(sigma), literal=literal, y=y,
+                            D_bits=np.packbits(r["D"][: code.N * F].astype(np.uint8)), flags=r["D"][code.N * F:],
+                            it=r["it"], hash=np.uint32(h))
+        print("binary %s: it=%d hash=%08x" % (tag, r["it"], h))
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    orc.build()
+    make_binary()
+    make_nb()

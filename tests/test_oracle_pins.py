@@ -1,0 +1,159 @@
+"""Pin the CPU oracle before anything is compared against it (CPU only).
+
+* binary path: D-hashes / anchor samples that SURVEY.md 8c + Appendix D.3
+  recorded from a host emulation of the reference's kernels (the reference has
+  no buildable CPU path for the binary decoder, so these are its only pins).
+* NB EMS path: bit-exact against dumps of the REFERENCE's own CPU decoder
+  (oracle/_ref/nb_ref built from /root/reference/myNBLDPC/src) committed under
+  tests/golden/nb_ref_*.npz, and against the reference fixture codeword
+  (include/codeword_test.h:1 -> data/nb/codeword_bds_gf64.txt).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN
+
+BL = os.path.join(DATA, "bldpc")
+NB = os.path.join(DATA, "nb")
+
+# (file, J, L, Z, F, Es/N0, literal, expected hash of D[0..N*F), expected iteraTime)  -- SURVEY.md 8c
+SURVEY_HASHES = [
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 3.0, False, 0x05A41534, 50),
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 4.0, False, 0x99F71DC5, 6),
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 5.0, False, 0x43A7F222, 3),
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 4.0, True, 0x90C5DF9B, 50),
+    ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 16, -1.0, False, 0xC00D92C5, None),
+    ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 16, 0.0, False, 0x5E509DC5, None),
+]
+# first sample y[0] of the first batch, J4_L24_Z96, F = 32
+Y0_ANCHORS = {2.0: 0.848695815, 3.0: 0.865149975, 4.0: 0.879814804, 5.0: 0.892884851, 6.0: 0.904533505}
+SIGMA_ANCHORS = {2.0: 0.561674893, 4.0: 0.446154207}
+
+
+@pytest.mark.parametrize("case", SURVEY_HASHES, ids=lambda c: "%s_%g_%s" % (c[0][:11], c[5], "lit" if c[6] else "cor"))
+def test_binary_oracle_matches_survey_hashes(orc, case):
+    name, J, L, Z, F, snr, literal, want, want_it = case
+    code = orc.BinaryCode(os.path.join(BL, name), J, L, Z, literal=literal)
+    seed = np.array([173, 173, 173], np.int32)
+    y = orc.bldpc_awgn(seed, orc.bldpc_sigma(snr), code.N, F)
+    r = orc.bldpc_decode(code, y, F, 50, early_exit=1)
+    assert orc.fold_hash(r["D"][: code.N * F]) == want
+    if want_it is not None:
+        assert r["it"] == want_it
+
+
+def test_binary_channel_anchors(orc):
+    for snr, want in Y0_ANCHORS.items():
+        seed = np.array([173, 173, 173], np.int32)
+        y = orc.bldpc_awgn(seed, orc.bldpc_sigma(snr), 2304, 32)
+        assert np.float32(y[0]) == np.float32(want)
+    for snr, want in SIGMA_ANCHORS.items():
+        assert np.float32(orc.bldpc_sigma(snr)) == np.float32(want)
+
+
+def test_binary_as_written_table_error_floor(orc):
+    # SURVEY F3 / BASELINE.md 2: reference Transform_H as written -> 7/32 frame errors at 6 dB
+    code = orc.BinaryCode(os.path.join(BL, "J4_L24_Z96_BlockH.txt"), 4, 24, 96, literal=True)
+    seed = np.array([173, 173, 173], np.int32)
+    y = orc.bldpc_awgn(seed, orc.bldpc_sigma(6.0), code.N, 32)
+    r = orc.bldpc_decode(code, y, 32, 50, early_exit=1)
+    assert int(r["D"][code.N * 32:].sum()) == 32 - 7
+
+
+def test_binary_golden_fixture_consistent(orc):
+    for fn in sorted(os.listdir(GOLDEN)):
+        if not fn.startswith("bldpc_"):
+            continue
+        g = np.load(os.path.join(GOLDEN, fn))
+        J, L, Z, F = int(g["J"]), int(g["L"]), int(g["Z"]), int(g["F"])
+        code = orc.BinaryCode(os.path.join(BL, "J%d_L%d_Z%d_BlockH.txt" % (J, L, Z)), J, L, Z, literal=bool(g["literal"]))
+        r = orc.bldpc_decode(code, g["y"], F, 50, early_exit=1)
+        D = np.unpackbits(g["D_bits"])[: code.N * F].astype(np.int32)
+        assert np.array_equal(r["D"][: code.N * F], D)
+        assert np.array_equal(r["D"][code.N * F:], g["flags"])
+        assert r["it"] == int(g["it"])
+        assert orc.fold_hash(D) == int(g["hash"])
+        # the stored y is what this box's libm regenerates (guards the channel restatement)
+        seed = np.array([173, 173, 173], np.int32)
+        y = orc.bldpc_awgn(seed, float(g["sigma"]), code.N, F)
+        assert np.array_equal(y.view(np.uint32), g["y"].view(np.uint32))
+
+
+# ----------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def nbcode(orc):
+    return orc.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+
+
+def test_nb_fixture_codeword_is_valid(orc, nbcode):
+    # codeword_test.h is a codeword of the BDS matrix (all 48 syndromes zero)
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    c = nbcode
+    mul = c.mul.reshape(c.q, c.q)
+    for row in range(c.M):
+        s = 0
+        for i in range(c.cn_w[row]):
+            s ^= int(mul[cw[c.cn_vn[row * c.dc + i]], c.cn_gf[row * c.dc + i]])
+        assert s == 0
+    assert np.array_equal(c.add.reshape(c.q, c.q), np.arange(c.q)[:, None] ^ np.arange(c.q)[None, :])
+
+
+@pytest.mark.parametrize("snr", [2, 3, 5])
+def test_nb_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr):
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%ddB.npz" % snr))
+    c = nbcode
+    sigma = float(g["sigma"])
+    assert np.float32(orc.nb_sigma(float(g["snr"]), c.rate)) == np.float32(sigma)
+    assert np.float32(c.rate) == np.float32(g["rate"])
+    # channel restatement reproduces the reference's rx stream
+    seed = np.array([173, 173, 173], np.int32)
+    full = {int(f): i for i, f in enumerate(g["full_frames"])}
+    for fr in range(g["rx"].shape[0]):
+        rx, Lch = orc.nb_channel(c, g["cw"], seed, sigma)
+        assert np.array_equal(rx.view(np.uint32), g["rx"][fr].view(np.uint32)), "rx frame %d" % fr
+        Lch = orc.nb_demodulate(c, g["rx"][fr], sigma)
+        assert orc.fold_hash(Lch) == int(g["Lch_hash"][fr])
+        r = orc.nb_ems_decode(c, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]), "frame %d" % fr
+        assert np.array_equal(r["out"], g["out"][fr])
+        assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]), "LLR frame %d" % fr
+        assert orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr]), "c2v frame %d" % fr
+        if fr in full:
+            i = full[fr]
+            assert np.array_equal(Lch.view(np.uint32), g["full_Lch"][i].view(np.uint32))
+            assert np.array_equal(r["LLR"].view(np.uint32), g["full_LLR"][i].view(np.uint32))
+            assert np.array_equal(r["c2v"].view(np.uint32), g["full_c2v"][i].view(np.uint32))
+
+
+def test_nb_survey_anchor_values(orc, nbcode):
+    # 3 dB, frame 0..3, L_ch of symbol 0 element 1; iteration counts
+    g = np.load(os.path.join(GOLDEN, "nb_ref_3dB.npz"))
+    assert np.float32(g["sigma"]) == np.float32(0.707945764)
+    assert list(g["it"][:8]) == [3, 4, 5, 7, 20, 20, 8, 12]
+    assert list(g["ok"][:8]) == [1, 1, 1, 1, 0, 0, 1, 1]
+    assert np.float32(g["full_Lch"][0][0, 0]) == np.float32(-3.2869091)
+    assert int((g["out"][4] != g["cw"]).sum()) == 9 and int((g["out"][5] != g["cw"]).sum()) == 63
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/myNBLDPC"), reason="reference tree absent (GPU box)")
+def test_nb_reference_binary_reproduces_golden(orc):
+    """Re-run the real reference here and compare with the committed dump (guards fixture drift)."""
+    import subprocess
+    import tempfile
+    import importlib.util
+    ref = orc.ref_binary()
+    if ref is None:
+        pytest.skip("oracle/_ref/nb_ref not built")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_3dB.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "d.bin")
+        subprocess.check_call([ref, "dump", "3.0", "8", out], cwd=NB, stdout=subprocess.DEVNULL)
+        d = mg.parse_nb_dump(out)
+    for fr, r in enumerate(d["recs"]):
+        assert np.array_equal(r["out"], g["out"][fr]) and r["it"] == int(g["it"][fr])
+        assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr])
