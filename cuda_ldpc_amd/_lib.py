@@ -1,0 +1,46 @@
+"""Loader of libcuda_ldpc_amd.so (the C ABI declared in include/bldpc.h, include/nbldpc.h)."""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- first, so that ONE HIP runtime (torch's) serves the whole process
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcuda_ldpc_amd.so")
+
+
+class ExtensionMissing(ImportError):
+    pass
+
+
+def load():
+    if not os.path.exists(SO_PATH):
+        raise ExtensionMissing(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback." % SO_PATH)
+    return ctypes.CDLL(SO_PATH)
+
+
+lib = load()
+
+c_int, c_void_p, c_char_p = ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
+lib.bldpc_last_error.restype = c_char_p
+lib.bldpc_last_kernel.restype = c_char_p
+lib.bldpc_last_kernel.argtypes = [c_void_p]
+lib.bldpc_read_blockh.argtypes = [c_char_p, c_int, c_int, c_void_p, c_void_p, c_void_p]
+lib.bldpc_transform_h.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]
+lib.bldpc_code_create_qc.argtypes = [c_int, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]
+lib.bldpc_code_create_table.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
+lib.bldpc_code_destroy.argtypes = [c_void_p]
+lib.bldpc_code_dims.argtypes = [c_void_p, c_void_p]
+lib.bldpc_decode.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                             ctypes.POINTER(c_int), c_void_p]
+lib.bldpc_statistic.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+
+
+class LdpcError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LdpcError("%s failed (%d): %s" % (what, rc, lib.bldpc_last_error().decode(errors="replace")))

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's binary LDPC entry points.
+
+Same names and argument meaning as bldpc_实习/{Simulation,LDPC_Decoder}.cu; the
+compile-time macros of define.cuh (J, L, Z, Num_Frames_OneTime, maxIT, msgLen)
+become run-time arguments.  Everything computes through the C ABI of
+include/bldpc.h on the GPU; tensors are torch CUDA(HIP) tensors.
+"""
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+EXIT_FIXED, EXIT_BATCH_GLOBAL = 0, 1
+KERNEL_AUTO, KERNEL_TABLE, KERNEL_QC_LDS = 0, 1, 2
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dev_ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def Get_H(path, J, L):
+    """Get_H (Simulation.cu:292-354): -> (H[J*L], Weight_Checknode[J+1], Weight_Variablenode[L+1]) int32 host arrays."""
+    H = np.zeros(J * L, np.int32)
+    wc = np.zeros(J + 1, np.int32)
+    wv = np.zeros(L + 1, np.int32)
+    check(lib.bldpc_read_blockh(str(path).encode(), J, L, _np_ptr(H), _np_ptr(wc), _np_ptr(wv)), "Get_H")
+    return H, wc, wv
+
+
+def Transform_H(H, J, L, Z, Weight_Checknode, Weight_Variablenode, as_written=False):
+    """Transform_H (Simulation.cu:363-387): -> Address_Variablenode[N*Wv] int32 (host)."""
+    H = np.ascontiguousarray(H, np.int32)
+    wc = np.ascontiguousarray(Weight_Checknode, np.int32)
+    wv = np.ascontiguousarray(Weight_Variablenode, np.int32)
+    addr = np.zeros(L * Z * int(wv[L]), np.int32)
+    check(lib.bldpc_transform_h(_np_ptr(H), J, L, Z, _np_ptr(wc), _np_ptr(wv), _np_ptr(addr), 1 if as_written else 0),
+          "Transform_H")
+    return addr
+
+
+class BinaryCode:
+    """Device-resident code object (bldpc_code).  Build with from_blockh / from_shifts / from_table."""
+
+    def __init__(self, handle, J, L, Z):
+        self._h = handle
+        self.J, self.L, self.Z = J, L, Z
+        d = np.zeros(8, np.int32)
+        check(lib.bldpc_code_dims(self._h, _np_ptr(d)), "bldpc_code_dims")
+        self.N, self.M, self.K, self.Wc, self.Wv, self.nnz, self.levels, self.frames_per_wg = (int(x) for x in d)
+
+    @classmethod
+    def from_shifts(cls, H, J, L, Z):
+        H = np.ascontiguousarray(H, np.int32)
+        if H.size != J * L:
+            raise ValueError("H must hold J*L shifts")
+        h = ctypes.c_void_p()
+        check(lib.bldpc_code_create_qc(J, L, Z, _np_ptr(H), ctypes.byref(h)), "bldpc_code_create_qc")
+        return cls(h, J, L, Z)
+
+    @classmethod
+    def from_blockh(cls, path, J, L, Z):
+        H, _, _ = Get_H(path, J, L)
+        return cls.from_shifts(H, J, L, Z)
+
+    @classmethod
+    def from_table(cls, J, L, Z, Weight_Checknode, Weight_Variablenode, Address_Variablenode):
+        wc = np.ascontiguousarray(Weight_Checknode, np.int32)
+        wv = np.ascontiguousarray(Weight_Variablenode, np.int32)
+        addr = np.ascontiguousarray(Address_Variablenode, np.int32)
+        if wc.size != J + 1 or wv.size != L + 1 or addr.size != L * Z * int(wv[L]):
+            raise ValueError("table shapes do not match J, L, Z")
+        h = ctypes.c_void_p()
+        check(lib.bldpc_code_create_table(J, L, Z, _np_ptr(wc), _np_ptr(wv), _np_ptr(addr), ctypes.byref(h)),
+              "bldpc_code_create_table")
+        return cls(h, J, L, Z)
+
+    @property
+    def last_kernel(self):
+        return lib.bldpc_last_kernel(self._h).decode()
+
+    def close(self):
+        if self._h:
+            lib.bldpc_code_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def LDPC_Decoder_GPU(code, Channel_Out, max_iter=50, length=0, exit_mode=EXIT_BATCH_GLOBAL, kernel=KERNEL_AUTO,
+                     D=None, want_app=False, want_flag_hist=False, stream=None):
+    """LDPC_Decoder_GPU (LDPC_Decoder.cu:23-164).
+
+    Channel_Out: CUDA float32 tensor [N, F] (frame-fastest, as the reference).
+    Returns dict(D=int32 [N+1, F] on device, iteraTime=int, app=[N, F] or None, flag_hist=uint64-as-int64 [F] or None).
+    """
+    if not (Channel_Out.is_cuda and Channel_Out.dtype == torch.float32 and Channel_Out.is_contiguous()):
+        raise ValueError("Channel_Out must be a contiguous CUDA float32 tensor")
+    if Channel_Out.dim() != 2 or Channel_Out.shape[0] != code.N:
+        raise ValueError("Channel_Out must be [N=%d, F]" % code.N)
+    F = int(Channel_Out.shape[1])
+    dev = Channel_Out.device
+    if D is None:
+        D = torch.empty((code.N + 1, F), dtype=torch.int32, device=dev)
+    app = torch.empty((code.N, F), dtype=torch.float32, device=dev) if want_app else None
+    hist = torch.zeros(F, dtype=torch.int64, device=dev) if want_flag_hist else None
+    it = ctypes.c_int(0)
+    st = ctypes.c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
+    check(lib.bldpc_decode(code._h, _dev_ptr(Channel_Out), F, max_iter, length, exit_mode, kernel, _dev_ptr(D), _dev_ptr(app),
+                           _dev_ptr(hist), ctypes.byref(it), st), "LDPC_Decoder_GPU")
+    return dict(D=D, iteraTime=it.value, app=app, flag_hist=hist)
+
+
+@dataclass
+class SimCounters:
+    """The counters of struct Simulation (struct.cuh:17-33)."""
+    num_Frames: int = 0
+    num_Error_Frames: int = 0
+    num_Error_Bits: int = 0
+    Total_Iteration: int = 0
+    num_False_Frames: int = 0
+    num_Alarm_Frames: int = 0
+    _dev: object = field(default=None, repr=False)
+
+    def ratios(self, length):
+        n = max(self.num_Frames, 1)
+        return dict(FER=self.num_Error_Frames / n, BER=self.num_Error_Bits / n / length, AverageIT=self.Total_Iteration / n,
+                    FER_False=self.num_False_Frames / n, FER_Alarm=self.num_Alarm_Frames / n)
+
+
+def Statistic(SIM, code, D, iteraTime, length=0, CodeWord=None, leastErrorFrames=50, leastTestFrames=10000, stream=None):
+    """Statistic (Simulation.cu:245-285) on the device; returns the reference's stop flag.
+
+    The caller adds the batch to SIM.num_Frames first, like Simulation_GPU does (Simulation.cu:113)."""
+    F = int(D.shape[1])
+    if SIM._dev is None:
+        SIM._dev = torch.zeros(5, dtype=torch.int64, device=D.device)
+    st = ctypes.c_void_p((stream or torch.cuda.current_stream(D.device)).cuda_stream)
+    check(lib.bldpc_statistic(code._h, _dev_ptr(D), _dev_ptr(CodeWord), F, length, iteraTime, _dev_ptr(SIM._dev), st), "Statistic")
+    c = SIM._dev.cpu().tolist()
+    SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, SIM.num_False_Frames, SIM.num_Alarm_Frames = c
+    return 1 if (SIM.num_Error_Frames >= leastErrorFrames and SIM.num_Frames >= leastTestFrames) else 0

@@ -1,0 +1,316 @@
+// bldpc_api.hip -- host side of the binary QC-LDPC decoder behind include/bldpc.h.
+//
+// Graph builders restate bldpc_实习/Simulation.cu:292-387 (Get_H, Transform_H);
+// bldpc_decode replaces LDPC_Decoder_GPU (LDPC_Decoder.cu:23-164): same inputs,
+// same D/iteraTime outputs, but no per-call allocation, no per-iteration
+// device->host copy of D and no host-side termination loop.
+#include "../../include/bldpc.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "bldpc_qc_kernel.hpp"
+#include "bldpc_table_kernels.hpp"
+#include "common.hpp"
+
+using namespace cldpc;
+
+struct bldpc_code {
+    int J = 0, L = 0, Z = 0, N = 0, M = 0, K = 0, Wc = 0, Wv = 0, nnz = 0, levels = 1;
+    bool has_qc = false;
+    std::vector<int> H, wc, wv;
+    std::vector<int> level_begin; // node_list range of each VN level, size levels+1
+    int *d_addr = nullptr, *d_node_list = nullptr;
+    unsigned char *d_wv_blk = nullptr, *d_wc_blk = nullptr;
+    DevBuf rq, bad, cnt;
+    int *h_cnt = nullptr; // pinned
+    QcPlan qc;            // fused LDS kernel description (frames_per_wg == 0: unavailable)
+    const char *last_kernel = "none";
+};
+
+extern "C" const char *bldpc_last_error(void) { return err_buf(); }
+
+extern "C" int bldpc_read_blockh(const char *path, int J, int L, int *H, int *wc, int *wv)
+{
+    if (!path || !H || !wc || !wv || J <= 0 || L <= 0) return fail(BLDPC_EINVAL, "bldpc_read_blockh: bad argument");
+    FILE *fp = fopen(path, "r");
+    if (!fp) return fail(BLDPC_EIO, "can not open file: %s", path);
+    for (int i = 0; i < J * L; i++) {
+        int v;
+        if (fscanf(fp, "%d", &v) != 1) {
+            fclose(fp);
+            return fail(BLDPC_EIO, "%s: expected %d shifts, got %d", path, J * L, i);
+        }
+        H[i] = v;
+    }
+    fclose(fp);
+    std::fill(wc, wc + J + 1, 0);
+    std::fill(wv, wv + L + 1, 0);
+    for (int j = 0; j < J; j++) {
+        for (int l = 0; l < L; l++) wc[j] += (H[j * L + l] != -1);
+        wc[J] = std::max(wc[J], wc[j]);
+    }
+    for (int l = 0; l < L; l++) {
+        for (int j = 0; j < J; j++) wv[l] += (H[j * L + l] != -1);
+        wv[L] = std::max(wv[L], wv[l]);
+    }
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_transform_h(const int *H, int J, int L, int Z, const int *wc, const int *wv, int *addr, int as_written)
+{
+    if (!H || !wc || !wv || !addr || J <= 0 || L <= 0 || Z <= 0) return fail(BLDPC_EINVAL, "bldpc_transform_h: bad argument");
+    const int Wv = wv[L], Wc = wc[J];
+    std::fill(addr, addr + (size_t)L * Z * Wv, -1);
+    for (int l = 0; l < L; l++) {
+        int k = 0;
+        for (int j = 0; j < J; j++) {
+            const int s = H[j * L + l];
+            if (s == -1) continue;
+            if (s < 0 || s >= Z) return fail(BLDPC_EINVAL, "shift %d of block (%d,%d) outside [0,%d)", s, j, l, Z);
+            int pos = 0; // ordinal of this block among the non-zero blocks of row j
+            for (int t = 0; t < l; t++) pos += (H[j * L + t] != -1);
+            for (int c = 0; c < Z; c++) {
+                int row;
+                if (as_written) // Simulation.cu:380, kept literally: the else branch is `c`
+                    row = (((Z - s) % Z + c) >= Z) ? (Z - s) % Z + c - Z : c;
+                else
+                    row = (c - s + Z) % Z;
+                addr[((size_t)l * Z + c) * Wv + k] = (j * Z + row) * Wc + pos;
+            }
+            k++;
+        }
+    }
+    return BLDPC_OK;
+}
+
+static int upload(void **dst, const void *src, size_t bytes)
+{
+    CLDPC_HIP(hipMalloc(dst, bytes), BLDPC_ENOMEM);
+    CLDPC_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), BLDPC_EHIP);
+    return BLDPC_OK;
+}
+
+// Shared tail of the two constructors: validate the table, level-schedule the
+// variable nodes, upload.
+static int finish_code(bldpc_code *c, const int *addr)
+{
+    const int N = c->N, Wv = c->Wv, slots = c->M * c->Wc;
+    if (c->Wv > kMaxWv || c->Wc > kMaxWc || c->Wv < 1 || c->Wc < 2)
+        return fail(BLDPC_EUNSUPPORTED, "block weights Wc=%d Wv=%d outside supported [2,%d] / [1,%d]", c->Wc, c->Wv, kMaxWc, kMaxWv);
+    std::vector<int> last(slots, 0), level(N, 1);
+    int levels = 1;
+    for (int n = 0; n < N; n++) {
+        const int w = c->wv[n / c->Z];
+        int lv = 1;
+        for (int i = 0; i < w; i++) {
+            const int s = addr[(size_t)n * Wv + i];
+            if (s < 0 || s >= slots) return fail(BLDPC_EINVAL, "Address_Variablenode[%d][%d] = %d outside [0,%d)", n, i, s, slots);
+            lv = std::max(lv, last[s] + 1);
+        }
+        for (int i = 0; i < w; i++) last[addr[(size_t)n * Wv + i]] = lv;
+        level[n] = lv;
+        levels = std::max(levels, lv);
+    }
+    c->levels = levels;
+    std::vector<int> order(N);
+    for (int n = 0; n < N; n++) order[n] = n;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
+    c->level_begin.assign(levels + 1, 0);
+    for (int n = 0; n < N; n++) c->level_begin[level[n]]++;
+    for (int l = 1; l <= levels; l++) c->level_begin[l] += c->level_begin[l - 1];
+    std::vector<unsigned char> wvb(c->L), wcb(c->J);
+    for (int l = 0; l < c->L; l++) wvb[l] = (unsigned char)c->wv[l];
+    for (int j = 0; j < c->J; j++) wcb[j] = (unsigned char)c->wc[j];
+    int r;
+    if ((r = upload((void **)&c->d_addr, addr, (size_t)N * Wv * sizeof(int)))) return r;
+    if (levels > 1 && (r = upload((void **)&c->d_node_list, order.data(), (size_t)N * sizeof(int)))) return r;
+    if ((r = upload((void **)&c->d_wv_blk, wvb.data(), wvb.size()))) return r;
+    if ((r = upload((void **)&c->d_wc_blk, wcb.data(), wcb.size()))) return r;
+    CLDPC_HIP(hipHostMalloc((void **)&c->h_cnt, sizeof(int), hipHostMallocDefault), BLDPC_ENOMEM);
+    return BLDPC_OK;
+}
+
+static int set_dims(bldpc_code *c, int J, int L, int Z)
+{
+    if (J <= 0 || L <= 0 || Z <= 0 || J >= L) return fail(BLDPC_EINVAL, "need 0 < J < L and Z > 0 (J=%d L=%d Z=%d)", J, L, Z);
+    if ((long long)L * Z > (1 << 24)) return fail(BLDPC_EUNSUPPORTED, "N = %lld too large", (long long)L * Z);
+    c->J = J; c->L = L; c->Z = Z;
+    c->N = L * Z; c->M = J * Z; c->K = c->N - c->M;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_code_create_qc(int J, int L, int Z, const int *H, bldpc_code **out)
+{
+    if (!H || !out) return fail(BLDPC_EINVAL, "bldpc_code_create_qc: null argument");
+    bldpc_code *c = new (std::nothrow) bldpc_code;
+    if (!c) return fail(BLDPC_ENOMEM, "out of host memory");
+    int r = set_dims(c, J, L, Z);
+    if (r) { delete c; return r; }
+    c->H.assign(H, H + J * L);
+    c->wc.assign(J + 1, 0);
+    c->wv.assign(L + 1, 0);
+    for (int j = 0; j < J; j++)
+        for (int l = 0; l < L; l++)
+            if (H[j * L + l] != -1) {
+                if (H[j * L + l] < 0 || H[j * L + l] >= Z) { delete c; return fail(BLDPC_EINVAL, "shift %d outside [0,%d)", H[j * L + l], Z); }
+                c->wc[j]++; c->wv[l]++; c->nnz++;
+            }
+    for (int j = 0; j < J; j++) c->wc[J] = std::max(c->wc[J], c->wc[j]);
+    for (int l = 0; l < L; l++) c->wv[L] = std::max(c->wv[L], c->wv[l]);
+    c->Wc = c->wc[J]; c->Wv = c->wv[L];
+    std::vector<int> addr((size_t)c->N * std::max(c->Wv, 1));
+    if (c->Wv < 1) { delete c; return fail(BLDPC_EINVAL, "empty matrix"); }
+    r = bldpc_transform_h(H, J, L, Z, c->wc.data(), c->wv.data(), addr.data(), 0);
+    if (!r) r = finish_code(c, addr.data());
+    if (!r) {
+        c->has_qc = true;
+        r = qc_plan_build(&c->qc, J, L, Z, c->H.data());
+    }
+    if (r) { bldpc_code_destroy(c); return r; }
+    *out = c;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_code_create_table(int J, int L, int Z, const int *wc, const int *wv, const int *addr, bldpc_code **out)
+{
+    if (!wc || !wv || !addr || !out) return fail(BLDPC_EINVAL, "bldpc_code_create_table: null argument");
+    bldpc_code *c = new (std::nothrow) bldpc_code;
+    if (!c) return fail(BLDPC_ENOMEM, "out of host memory");
+    int r = set_dims(c, J, L, Z);
+    if (r) { delete c; return r; }
+    c->wc.assign(wc, wc + J + 1);
+    c->wv.assign(wv, wv + L + 1);
+    c->Wc = wc[J]; c->Wv = wv[L];
+    for (int j = 0; j < J; j++) {
+        if (wc[j] < 0 || wc[j] > c->Wc) { delete c; return fail(BLDPC_EINVAL, "Weight_Checknode[%d]=%d > max %d", j, wc[j], c->Wc); }
+        c->nnz += wc[j];
+    }
+    for (int l = 0; l < L; l++)
+        if (wv[l] < 0 || wv[l] > c->Wv) { delete c; return fail(BLDPC_EINVAL, "Weight_Variablenode[%d]=%d > max %d", l, wv[l], c->Wv); }
+    r = finish_code(c, addr);
+    if (r) { bldpc_code_destroy(c); return r; }
+    *out = c;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_code_destroy(bldpc_code *c)
+{
+    if (!c) return BLDPC_OK;
+    if (c->d_addr) (void)hipFree(c->d_addr);
+    if (c->d_node_list) (void)hipFree(c->d_node_list);
+    if (c->d_wv_blk) (void)hipFree(c->d_wv_blk);
+    if (c->d_wc_blk) (void)hipFree(c->d_wc_blk);
+    if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+    c->rq.release(); c->bad.release(); c->cnt.release();
+    qc_plan_release(&c->qc);
+    delete c;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_code_dims(const bldpc_code *c, int dims[8])
+{
+    if (!c || !dims) return fail(BLDPC_EINVAL, "bldpc_code_dims: null argument");
+    dims[0] = c->N; dims[1] = c->M; dims[2] = c->K; dims[3] = c->Wc; dims[4] = c->Wv; dims[5] = c->nnz;
+    dims[6] = c->levels; dims[7] = c->has_qc ? c->qc.frames_per_wg : 0;
+    return BLDPC_OK;
+}
+
+extern "C" const char *bldpc_last_kernel(const bldpc_code *c) { return c ? c->last_kernel : "none"; }
+
+// ---------------------------------------------------------------------------
+template <int VEC>
+static int run_table(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
+                     unsigned long long *flag_hist, int *itera, hipStream_t st)
+{
+    TableArgs a;
+    a.rq = (float *)c->rq.p; a.y = y; a.addr = c->d_addr; a.node_list = c->d_node_list;
+    a.wv_blk = c->d_wv_blk; a.wc_blk = c->d_wc_blk;
+    a.F = F; a.Z = c->Z; a.Wv = c->Wv; a.Wc = c->Wc; a.length = length;
+    int *bad = (int *)c->bad.p, *cnt = (int *)c->cnt.p;
+    const dim3 blk(256);
+    const unsigned gx = (unsigned)((F + VEC * 256 - 1) / (VEC * 256));
+    const bool per_iter_flags = (exit_mode == BLDPC_EXIT_BATCH_GLOBAL) || flag_hist;
+    CLDPC_HIP(hipMemsetAsync(c->rq.p, 0, (size_t)c->M * c->Wc * F * sizeof(float), st), BLDPC_EHIP); // LDPC_Decoder.cu:82
+    CLDPC_HIP(hipMemsetAsync(bad, 0, (size_t)F * sizeof(int), st), BLDPC_EHIP);
+    if (flag_hist) CLDPC_HIP(hipMemsetAsync(flag_hist, 0, (size_t)F * sizeof(unsigned long long), st), BLDPC_EHIP);
+    int it = 0;
+    while (it < max_iter) {
+        it++;
+        const bool last = (it == max_iter);
+        const bool want_out = last || exit_mode == BLDPC_EXIT_BATCH_GLOBAL; // D must be current whenever we may stop
+        a.D = want_out ? D : nullptr;
+        a.app = (want_out && app) ? app : nullptr;
+        a.bad = (per_iter_flags || last) ? bad : nullptr;
+        for (int lv = 0; lv < c->levels; lv++) { // one launch per collision level (1 for a conflict-free table)
+            const int n0 = c->level_begin[lv], cntn = c->level_begin[lv + 1] - n0;
+            if (cntn <= 0) continue;
+            hipLaunchKernelGGL(k_table_vn<VEC>, dim3(gx, (unsigned)std::min(cntn, 65535)), blk, 0, st, a, n0, cntn);
+        }
+        if (!last || exit_mode == BLDPC_EXIT_BATCH_GLOBAL) // the CN pass after the final VN pass is unobservable
+            hipLaunchKernelGGL(k_table_cn<VEC>, dim3(gx, (unsigned)std::min(c->M, 65535)), blk, 0, st, a, c->M);
+        if (per_iter_flags || last) {
+            const bool need_cnt = exit_mode == BLDPC_EXIT_BATCH_GLOBAL;
+            if (need_cnt) CLDPC_HIP(hipMemsetAsync(cnt, 0, sizeof(int), st), BLDPC_EHIP);
+            hipLaunchKernelGGL(k_flags, dim3((F + 255) / 256), blk, 0, st, bad, want_out ? D + (size_t)c->N * F : nullptr,
+                               flag_hist, need_cnt ? cnt : nullptr, F, it);
+            if (need_cnt) {
+                CLDPC_HIP(hipMemcpyAsync(c->h_cnt, cnt, sizeof(int), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
+                CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
+                if (*c->h_cnt == F) break; // LDPC_Decoder.cu:150-153
+            }
+        }
+    }
+    CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
+    *itera = it;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int kernel, int *D,
+                            float *app, unsigned long long *flag_hist, int *itera, void *stream)
+{
+    if (!c || !y || !D || !itera) return fail(BLDPC_EINVAL, "bldpc_decode: null argument");
+    if (F <= 0 || max_iter <= 0) return fail(BLDPC_EINVAL, "bldpc_decode: F=%d max_iter=%d must be positive", F, max_iter);
+    if (length == 0) length = c->K;
+    if (length < 0 || length > c->N) return fail(BLDPC_EINVAL, "bldpc_decode: length=%d outside [0,%d]", length, c->N);
+    if (exit_mode != BLDPC_EXIT_FIXED && exit_mode != BLDPC_EXIT_BATCH_GLOBAL) return fail(BLDPC_EINVAL, "unknown exit_mode %d", exit_mode);
+    hipStream_t st = (hipStream_t)stream;
+    const bool qc_ok = c->has_qc && c->qc.frames_per_wg > 0;
+    if (kernel == BLDPC_KERNEL_AUTO) kernel = qc_ok ? BLDPC_KERNEL_QC_LDS : BLDPC_KERNEL_TABLE;
+    if (kernel == BLDPC_KERNEL_QC_LDS) {
+        if (!qc_ok)
+            return fail(BLDPC_EUNSUPPORTED, "QC_LDS kernel unavailable for this code (%s)",
+                        c->has_qc ? "message state exceeds LDS" : "built from an address table");
+        CLDPC_HIP(c->bad.reserve((size_t)F * sizeof(unsigned long long)), BLDPC_ENOMEM);
+        CLDPC_HIP(c->cnt.reserve(64), BLDPC_ENOMEM);
+        int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
+                          (unsigned long long *)c->cnt.p, c->h_cnt, itera, st);
+        c->last_kernel = c->qc.name;
+        return r;
+    }
+    if (kernel != BLDPC_KERNEL_TABLE) return fail(BLDPC_EINVAL, "unknown kernel %d", kernel);
+    CLDPC_HIP(c->rq.reserve((size_t)c->M * c->Wc * F * sizeof(float)), BLDPC_ENOMEM);
+    CLDPC_HIP(c->bad.reserve((size_t)F * sizeof(unsigned long long)), BLDPC_ENOMEM);
+    CLDPC_HIP(c->cnt.reserve(64), BLDPC_ENOMEM);
+    const bool a16 = ((uintptr_t)y % 16 == 0) && ((uintptr_t)D % 16 == 0) && (!app || (uintptr_t)app % 16 == 0);
+    if (F % 4 == 0 && a16) {
+        c->last_kernel = "table_vec4";
+        return run_table<4>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+    }
+    c->last_kernel = "table_vec1";
+    return run_table<1>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+}
+
+extern "C" int bldpc_statistic(const bldpc_code *c, const int *D, const int *cw, int F, int length, int itera, long long *counters,
+                               void *stream)
+{
+    if (!c || !D || !counters || F <= 0) return fail(BLDPC_EINVAL, "bldpc_statistic: bad argument");
+    if (length == 0) length = c->K;
+    if (length < 0 || length > c->N) return fail(BLDPC_EINVAL, "bldpc_statistic: length=%d outside [0,%d]", length, c->N);
+    hipLaunchKernelGGL(k_statistic, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, D, cw, c->N, F, length, itera, counters);
+    CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
+    return BLDPC_OK;
+}

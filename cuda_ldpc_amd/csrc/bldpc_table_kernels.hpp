@@ -1,0 +1,192 @@
+// bldpc_table_kernels.hpp -- generic address-table kernels (BLDPC_KERNEL_TABLE).
+//
+// Messages live in HBM as rq[slot][F] (slot = m*Wc + p, frame-fastest), the
+// layout the reference's Address_Variablenode table is defined against
+// (bldpc_实习/Simulation.cu:363-387, LDPC_Decoder.cu:186-196).  They accept ANY
+// table, including the as-written one, and any code size; the QC kernel in
+// bldpc_qc_kernel.hpp is the fast path for codes whose state fits LDS.
+//
+// Differences from the reference's kernel pair: one workgroup row per node so
+// the table entries are wave-uniform scalar loads, VEC frames per lane with
+// 16-byte accesses, hard bits written only when someone will read them, the
+// per-frame termination flag folded into the VN pass (the reference copies all
+// of D to the host every iteration, LDPC_Decoder.cu:135-149).
+#pragma once
+#include "bldpc_math.hpp"
+
+namespace cldpc {
+
+constexpr int kMaxWv = 16; // reference bound: R[15] (LDPC_Decoder.cu:175)
+constexpr int kMaxWc = 26; // reference bound: Q[25] (LDPC_Decoder.cu:267)
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using f = float; using i = int; };
+template <> struct VecT<2> { using f = float2; using i = int2; };
+template <> struct VecT<4> { using f = float4; using i = int4; };
+
+template <int VEC> __device__ __forceinline__ void vload(float (&d)[VEC], const float *p)
+{
+    typename VecT<VEC>::f v = *reinterpret_cast<const typename VecT<VEC>::f *>(p);
+    __builtin_memcpy(d, &v, sizeof(v));
+}
+template <int VEC> __device__ __forceinline__ void vstore(float *p, const float (&s)[VEC])
+{
+    typename VecT<VEC>::f v;
+    __builtin_memcpy(&v, s, sizeof(v));
+    *reinterpret_cast<typename VecT<VEC>::f *>(p) = v;
+}
+template <int VEC> __device__ __forceinline__ void vstore_i(int *p, const int (&s)[VEC])
+{
+    typename VecT<VEC>::i v;
+    __builtin_memcpy(&v, s, sizeof(v));
+    *reinterpret_cast<typename VecT<VEC>::i *>(p) = v;
+}
+
+struct TableArgs {
+    float *rq;              // [M*Wc][F]
+    const float *y;         // [N][F]
+    const int *addr;        // [N][Wv]
+    const int *node_list;   // VN order by level (nullptr = identity)
+    const unsigned char *wv_blk; // [L]
+    const unsigned char *wc_blk; // [J]
+    int *D;                 // [N+1][F] or nullptr (skip hard-bit store this pass)
+    float *app;             // [N][F] or nullptr
+    int *bad;               // [F] set to 1 when a frame has a 1 among its first `length` bits (nullptr = skip)
+    int F, Z, Wv, Wc, length;
+};
+
+// Variable-node pass over nodes node_list[n0 .. n0+count) (LDPC_Decoder.cu:172-211).
+// grid = (ceil(F / (VEC*256)), min(count, 65535)); block = 256.
+template <int VEC> __global__ __launch_bounds__(256) void k_table_vn(TableArgs a, int n0, int count)
+{
+    const int f = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (f >= a.F) return;
+    for (int k = blockIdx.y; k < count; k += gridDim.y) {
+        const int n = a.node_list ? a.node_list[n0 + k] : n0 + k; // wave-uniform
+        const int w = a.wv_blk[n / a.Z];
+        const int *ad = a.addr + (size_t)n * a.Wv;
+        float R[kMaxWv][VEC];
+        float S[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) S[v] = 0.0f; // Add_result defined as 0
+#pragma unroll
+        for (int i = 0; i < kMaxWv; i++)
+            if (i < w) vload<VEC>(R[i], a.rq + (size_t)ad[i] * a.F + f);
+#pragma unroll
+        for (int i = 0; i < kMaxWv; i++)
+            if (i < w) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) S[v] += R[i][v];
+            }
+        float yv[VEC];
+        vload<VEC>(yv, a.y + (size_t)n * a.F + f);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) S[v] += yv[v];
+#pragma unroll
+        for (int i = 0; i < kMaxWv; i++)
+            if (i < w) {
+                float Q[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) Q[v] = S[v] - R[i][v];
+                vstore<VEC>(a.rq + (size_t)ad[i] * a.F + f, Q);
+            }
+        if (a.D) {
+            int d[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) d[v] = (S[v] < 0) ? 1 : 0;
+            vstore_i<VEC>(a.D + (size_t)n * a.F + f, d);
+        }
+        if (a.app) vstore<VEC>(a.app + (size_t)n * a.F + f, S);
+        if (a.bad && n < a.length) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++)
+                if (S[v] < 0) a.bad[f + v] = 1; // every writer stores the same value
+        }
+    }
+}
+
+// Check-node pass over all M rows (LDPC_Decoder.cu:262-315).
+// grid = (ceil(F / (VEC*256)), min(M, 65535)); block = 256.
+template <int VEC> __global__ __launch_bounds__(256) void k_table_cn(TableArgs a, int M)
+{
+    const int f = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (f >= a.F) return;
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        const int w = a.wc_blk[m / a.Z];
+        float *row = a.rq + (size_t)m * a.Wc * a.F + f;
+        float Q[kMaxWc][VEC];
+        CnAcc acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v].init();
+#pragma unroll
+        for (int i = 0; i < kMaxWc; i++)
+            if (i < w) vload<VEC>(Q[i], row + (size_t)i * a.F);
+#pragma unroll
+        for (int i = 0; i < kMaxWc; i++)
+            if (i < w) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v].add(Q[i][v]);
+            }
+        uint32_t key[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) key[v] = acc[v].key();
+#pragma unroll
+        for (int i = 0; i < kMaxWc; i++)
+            if (i < w) {
+                float R[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) R[v] = cn_out(Q[i][v], acc[v].m2, key[v]);
+                vstore<VEC>(row + (size_t)i * a.F, R);
+            }
+    }
+}
+
+// Per-frame termination bookkeeping after one iteration (LDPC_Decoder.cu:134-153):
+//   flag = !bad; D[N][f] = flag; flag_hist bit; count frames whose flag is set; reset bad.
+__global__ __launch_bounds__(256) void k_flags(int *bad, int *D_flag_row, unsigned long long *flag_hist, int *ok_count,
+                                               int F, int it)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    int flag = 0;
+    if (f < F) {
+        flag = bad[f] ? 0 : 1;
+        bad[f] = 0;
+        if (D_flag_row) D_flag_row[f] = flag;
+        if (flag_hist && flag && it <= 64) flag_hist[f] |= (1ull << (it - 1));
+    }
+    if (ok_count) {
+        unsigned long long b = __ballot(flag);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(ok_count, __popcll(b));
+    }
+}
+
+// Device-side Statistic (Simulation.cu:245-262): one thread per frame.
+__global__ __launch_bounds__(256) void k_statistic(const int *D, const int *cw, int N, int F, int length, int itera,
+                                                   long long *counters)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    long long err_frames = 0, err_bits = 0, its = 0, fals = 0, alarm = 0;
+    if (f < F) {
+        int err = 0;
+        for (int k = 0; k < length; k++) {
+            int c = cw ? cw[(size_t)k * F + f] : 0;
+            err += (D[(size_t)k * F + f] != c) ? 1 : 0;
+        }
+        const int flag = D[(size_t)N * F + f];
+        err_bits = err;
+        err_frames = (err != 0 || flag == 0) ? 1 : 0;
+        alarm = (err == 0 && flag == 0) ? 1 : 0;
+        fals = (err != 0 && flag == 1) ? 1 : 0;
+        its = itera;
+    }
+    // wave reduction, then one atomic per wave and counter
+    long long v[5] = {err_frames, err_bits, its, fals, alarm};
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        long long x = v[c];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long *)&counters[c], (unsigned long long)x);
+    }
+}
+
+} // namespace cldpc

@@ -1,0 +1,228 @@
+"""GPU parity tests of the binary QC-LDPC decoder (through the C ABI, include/bldpc.h).
+
+Every comparison is bit-exact: hard bits, flags, iteration counts AND the float
+a-posteriori sums (compared as uint32 bit patterns) against the CPU oracle
+(oracle/bldpc_oracle.c, pinned in test_oracle_pins.py) and against the committed
+golden fixtures.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DATA, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+BL = os.path.join(DATA, "bldpc")
+
+
+@pytest.fixture(scope="module")
+def C():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cuda_ldpc_amd
+    return cuda_ldpc_amd
+
+
+def _path(J, L, Z):
+    return os.path.join(BL, "J%d_L%d_Z%d_BlockH.txt" % (J, L, Z))
+
+
+def _channel(orc, N, F, snr, seed=(173, 173, 173)):
+    s = np.array(seed, np.int32)
+    return orc.bldpc_awgn(s, orc.bldpc_sigma(snr), N, F)
+
+
+def _decode(C, code, y, F, **kw):
+    yt = torch.from_numpy(np.ascontiguousarray(y).reshape(code.N, F)).cuda()
+    r = C.LDPC_Decoder_GPU(code, yt, **kw)
+    torch.cuda.synchronize()
+    out = dict(D=r["D"].cpu().numpy().reshape(-1), it=r["iteraTime"])
+    out["app"] = None if r["app"] is None else r["app"].cpu().numpy().reshape(-1)
+    out["flag_hist"] = None if r["flag_hist"] is None else r["flag_hist"].cpu().numpy().view(np.uint64)
+    return out
+
+
+def _assert_same(got, want, N, F, check_app=True):
+    assert got["it"] == want["it"]
+    assert np.array_equal(got["D"][: N * F], want["D"][: N * F]), "hard bits differ"
+    assert np.array_equal(got["D"][N * F:], want["D"][N * F:]), "flag row differs"
+    if check_app and got["app"] is not None:
+        assert np.array_equal(got["app"].view(np.uint32), want["app"].view(np.uint32)), "a-posteriori LLRs differ bitwise"
+
+
+KERNELS = ["table", "qc"]
+
+
+def _k(C, name):
+    return C.KERNEL_TABLE if name == "table" else C.KERNEL_QC_LDS
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("fn", ["bldpc_J4_L24_Z96_3dB_cor.npz", "bldpc_J32_L64_Z64_-1dB_cor.npz"])
+def test_golden_fixture_batch_global(C, orc, kern, fn):
+    """Reference semantics end to end: batch-global early exit, D + flags + iteraTime vs the committed fixture."""
+    g = np.load(os.path.join(GOLDEN, fn))
+    J, L, Z, F = int(g["J"]), int(g["L"]), int(g["Z"]), int(g["F"])
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    r = _decode(C, code, g["y"], F, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL, kernel=_k(C, kern))
+    D = np.unpackbits(g["D_bits"])[: code.N * F].astype(np.int32)
+    assert r["it"] == int(g["it"])
+    assert np.array_equal(r["D"][: code.N * F], D)
+    assert np.array_equal(r["D"][code.N * F:], g["flags"])
+    assert orc.fold_hash(r["D"][: code.N * F]) == int(g["hash"])  # the hash SURVEY.md 8c recorded
+    assert (kern == "qc") == code.last_kernel.startswith("qc_lds")
+
+
+def test_golden_as_written_table(C, orc):
+    """The reference's Transform_H as written (colliding slots): table kernel, level-scheduled VN order."""
+    g = np.load(os.path.join(GOLDEN, "bldpc_J4_L24_Z96_4dB_lit.npz"))
+    J, L, Z, F = 4, 24, 96, int(g["F"])
+    H, wc, wv = C.Get_H(_path(J, L, Z), J, L)
+    addr = C.Transform_H(H, J, L, Z, wc, wv, as_written=True)
+    code = C.BinaryCode.from_table(J, L, Z, wc, wv, addr)
+    assert code.levels > 1 and code.frames_per_wg == 0
+    r = _decode(C, code, g["y"], F, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL)
+    assert orc.fold_hash(r["D"][: code.N * F]) == 0x90C5DF9B
+    assert np.array_equal(r["D"][code.N * F:], g["flags"]) and r["it"] == int(g["it"])
+    with pytest.raises(Exception):
+        _decode(C, code, g["y"], F, kernel=C.KERNEL_QC_LDS)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("iters", [1, 2, 3, 7, 50])
+def test_per_iteration_llr_bit_exact(C, orc, kern, iters):
+    """Per-iteration a-posteriori LLRs (north_star: within 1e-5; we require bitwise equality)."""
+    J, L, Z, F = 4, 24, 96, 16
+    y = _channel(orc, L * Z, F, 3.0)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, iters, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=_k(C, kern), want_app=True, want_flag_hist=True)
+    _assert_same(got, want, code.N, F)
+    mask = np.uint64((1 << min(iters, 64)) - 1)
+    assert np.array_equal(got["flag_hist"] & mask, want["flag_hist"] & mask)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("F", [1, 3, 4, 6, 37])
+def test_ragged_batches(C, orc, kern, F):
+    J, L, Z = 4, 24, 96
+    y = _channel(orc, L * Z, F, 3.5)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    for mode, ee in ((C.EXIT_FIXED, 0), (C.EXIT_BATCH_GLOBAL, 1)):
+        want = orc.bldpc_decode(ocode, y, F, 20, early_exit=ee, want_app=True)
+        got = _decode(C, code, y, F, max_iter=20, exit_mode=mode, kernel=_k(C, kern), want_app=True)
+        _assert_same(got, want, code.N, F)
+
+
+# every matrix family the reference ships; kernel the product picks by itself
+MATRICES = [(4, 24, 96, 3.0), (6, 24, 96, 2.0), (8, 24, 96, 1.0), (12, 24, 96, 0.0), (32, 64, 64, -0.5), (4, 24, 256, 3.0),
+            (4, 24, 512, 3.0), (10, 60, 160, 2.5), (48, 60, 160, -3.0), (15, 30, 1280, -0.5)]
+
+
+@pytest.mark.parametrize("J,L,Z,snr", MATRICES)
+def test_matrix_families_auto_kernel(C, orc, J, L, Z, snr):
+    F = 8
+    y = _channel(orc, L * Z, F, snr)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 12, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=12, exit_mode=C.EXIT_FIXED, want_app=True)
+    _assert_same(got, want, code.N, F)
+    if code.frames_per_wg:  # also cross-check the generic kernel on the same code
+        got2 = _decode(C, code, y, F, max_iter=12, exit_mode=C.EXIT_FIXED, kernel=C.KERNEL_TABLE, want_app=True)
+        _assert_same(got2, want, code.N, F)
+
+
+def test_pon_matrix(C, orc):
+    J, L, Z, F = 12, 69, 256, 4
+    p = os.path.join(BL, "PON_LDPC.txt")
+    y = _channel(orc, L * Z, F, 2.0)
+    ocode = orc.BinaryCode(p, J, L, Z)
+    code = C.BinaryCode.from_blockh(p, J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 10, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=10, exit_mode=C.EXIT_FIXED, want_app=True)
+    _assert_same(got, want, code.N, F)
+
+
+def test_special_values(C, orc):
+    """Zeros, denormals, huge magnitudes, exact ties (duplicate minima) -- still bitwise equal."""
+    J, L, Z, F = 4, 24, 96, 8
+    rng = np.random.default_rng(7)
+    N = L * Z
+    y = rng.standard_normal(N * F).astype(np.float32)
+    y[rng.integers(0, N * F, 2000)] = 0.0
+    y[rng.integers(0, N * F, 2000)] = -0.0
+    y[rng.integers(0, N * F, 2000)] = 1e-41       # denormal
+    y[rng.integers(0, N * F, 2000)] = -3e-42
+    y[rng.integers(0, N * F, 500)] = 3e38
+    y[rng.integers(0, N * F, 500)] = -3e38
+    y[rng.integers(0, N * F, 4000)] = 0.5          # ties
+    y[rng.integers(0, N * F, 4000)] = -0.5
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 6, early_exit=0, want_app=True)
+    for kern in KERNELS:
+        got = _decode(C, code, y, F, max_iter=6, exit_mode=C.EXIT_FIXED, kernel=_k(C, kern), want_app=True)
+        _assert_same(got, want, code.N, F)
+
+
+def test_full_size_batch_properties(C, orc):
+    """BASELINE config 2 at full size (65536 frames): a 64-frame oracle-checked block tiled 1024 times.
+
+    Size-independent properties: every tile decodes to the same bits (frames are independent), and the
+    first tile equals the oracle."""
+    J, L, Z, Fb, reps = 4, 24, 96, 64, 1024
+    N = L * Z
+    y = _channel(orc, N, Fb, 3.0).reshape(N, Fb)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y.reshape(-1), Fb, 50, early_exit=0)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    yt = torch.from_numpy(y).cuda().repeat(1, reps).contiguous()
+    r = C.LDPC_Decoder_GPU(code, yt, max_iter=50, exit_mode=C.EXIT_FIXED)
+    torch.cuda.synchronize()
+    assert code.last_kernel.startswith("qc_lds")
+    D = r["D"].view(N + 1, reps, Fb)
+    assert bool((D == D[:, :1, :]).all())
+    got = D[:, 0, :].contiguous().cpu().numpy().reshape(-1)
+    assert np.array_equal(got, want["D"])
+    # all-zero codeword, noiseless: decodes to zero with every flag set
+    clean = torch.ones((N, 256), dtype=torch.float32, device="cuda")
+    r2 = C.LDPC_Decoder_GPU(code, clean, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL)
+    assert r2["iteraTime"] == 1 and int(r2["D"][:N].sum()) == 0 and int(r2["D"][N].sum()) == 256
+
+
+def test_statistic_matches_oracle(C, orc):
+    J, L, Z, F = 4, 24, 96, 32
+    y = _channel(orc, L * Z, F, 2.5)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 50, early_exit=1)
+    cnt = np.zeros(5, np.int64)
+    stop_want = orc.bldpc_statistic(cnt, F, want["D"], ocode.N, F, ocode.K, want["it"], least_err=5, least_frames=32)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    yt = torch.from_numpy(y.reshape(code.N, F)).cuda()
+    r = C.LDPC_Decoder_GPU(code, yt, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL)
+    SIM = C.SimCounters()
+    SIM.num_Frames += F
+    stop = C.Statistic(SIM, code, r["D"], r["iteraTime"], leastErrorFrames=5, leastTestFrames=32)
+    assert [SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, SIM.num_False_Frames, SIM.num_Alarm_Frames] == list(cnt)
+    assert stop == stop_want
+
+
+def test_argument_errors(C):
+    J, L, Z = 4, 24, 96
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    y = torch.zeros((code.N, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(Exception):
+        C.LDPC_Decoder_GPU(code, y, max_iter=0)
+    with pytest.raises(Exception):
+        C.LDPC_Decoder_GPU(code, y, length=code.N + 1)
+    with pytest.raises(Exception):
+        C.Get_H("/nonexistent/file.txt", J, L)
+    bad = np.full(J * L, Z + 5, np.int32)
+    with pytest.raises(Exception):
+        C.BinaryCode.from_shifts(bad, J, L, Z)
