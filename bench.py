@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded codewords/s of the LDPC hot path on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--kernel auto|qc|table]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the decode hot path (bldpc_decode: 50 flooding min-sum iterations, early exit
+off, followed by the device-side error statistics) over one batch of synthetic channel values that are
+already resident in HBM.  Workload (BASELINE.json configs[1]): J4_L24_Z96 rate-5/6, 65536 codewords
+per GPU, Es/N0 = 3.0 dB, all-zero codeword, reference AWGN stream (seeds 173/173/173): a 4096-frame
+block generated once on the host and tiled to the batch.  Frames shard across ranks
+with no data-path collective (weak scaling); RCCL carries only the final all-reduce of the five error
+counters.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM (the bound
+SURVEY.md 8d prescribes): algorithmic bytes = (8N+4) per codeword * codewords per launch over the
+kernel's average duration measured with HIP events around the decode call alone.  `cpu_baseline` times
+the CPU oracle (a port of the reference kernels -- the binary reference has no CPU decode path) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (file, J, L, Z, frames per GPU, Es/N0 dB, iterations)
+    "J4_L24_Z96": ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 65536, 3.0, 50),
+    "J32_L64_Z64": ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 32768, 0.0, 50),
+    "J15_L30_Z1280": ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, 1024, 0.0, 50),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="J4_L24_Z96", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "qc", "table"])
+    ap.add_argument("--frames", type=int, default=0, help="override frames per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the cpu_baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
+    """Oracle (CPU port of the reference kernels, OpenMP over frames) on a bounded sample. Checker code,
+    used here ONLY as the reported CPU baseline -- never on the product path."""
+    from oracle import pyoracle as orc
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    code = orc.BinaryCode(os.path.join(ROOT, "data", "bldpc", name), J, L, Z)
+    if nframes <= 0:
+        nframes = 128 * cores  # ~115 cw/s/core at 50 iterations -> on the order of 10-20 s of CPU work
+    nframes = min(nframes, y_block.shape[1])
+    y = np.ascontiguousarray(y_block[:, :nframes]).reshape(-1)
+    orc.bldpc_decode(code, y, nframes, 1, early_exit=0)  # touch pages / spin up the OpenMP threads
+    t0 = time.perf_counter()
+    orc.bldpc_decode(code, y, nframes, iters, early_exit=0)
+    dt = time.perf_counter() - t0
+    return {"value": nframes / dt, "unit": "codewords/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same 4096-frame block, %d iterations, oracle/bldpc_oracle.c with OpenMP over frames, %.1f s"
+                      % (nframes, iters, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+
+    import cuda_ldpc_amd as C  # raises if the HIP extension is missing: no fallback
+
+    name, J, L, Z, frames, snr, iters = WORKLOADS[args.workload]
+    if args.frames:
+        frames = args.frames
+    code = C.BinaryCode.from_blockh(os.path.join(ROOT, "data", "bldpc", name), J, L, Z)
+    kernel = {"auto": C.KERNEL_AUTO, "qc": C.KERNEL_QC_LDS, "table": C.KERNEL_TABLE}[args.kernel]
+    N = code.N
+
+    # synthetic input: reference AWGN stream, one 4096-frame block tiled to the batch (host generation is
+    # serial: 2 LCG draws + 3 libm calls per sample, SURVEY 7 "hard parts")
+    block = min(4096, frames)
+    seed = np.array([173, 173, 173], np.int32)
+    y_block = C.AWGNChannel_CPU(seed, C.sigma_of(snr), N, block)  # [N, block]
+    reps = (frames + block - 1) // block
+    y = torch.from_numpy(y_block).to(dev).repeat(1, reps)[:, :frames].contiguous()
+    D = torch.empty((N + 1, frames), dtype=torch.int32, device=dev)
+    SIM = C.SimCounters()
+    SIM._dev = torch.zeros(5, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    import ctypes
+    from cuda_ldpc_amd._lib import check, lib
+
+    def step():
+        r = C.LDPC_Decoder_GPU(code, y, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
+        check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, frames, 0, r["iteraTime"],
+                                  ctypes.c_void_p(SIM._dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream)), "Statistic")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    SIM._dev.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
+        r = C.LDPC_Decoder_GPU(code, y, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
+        ev[k][1].record(stream)
+        check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, frames, 0, r["iteraTime"],
+                                  ctypes.c_void_p(SIM._dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream)), "Statistic")
+    counters = SIM._dev.clone()
+    if world > 1:
+        dist.all_reduce(counters)  # the only collective: 5 int64 error counters
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    if rank == 0:
+        total_cw = frames * world * args.steps
+        alg_bytes = (8 * N + 4) * frames  # fp32 LLR in + int32 hard bits out + flag, per launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        c = counters.cpu().tolist()
+        out = {
+            "metric": "decoded codewords/sec (50-iter flooding min-sum, fixed iterations)",
+            "value": total_cw / elapsed, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s rate-%.3f batch=%d codewords/GPU %d iters Es/N0=%.1fdB" % (args.workload, code.K / N, frames, iters, snr),
+                       "kernel": code.last_kernel, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "stats": {"frames": frames * world * args.steps, "error_frames": c[0], "error_bits": c[1],
+                      "FER": c[0] / (frames * world * args.steps), "BER": c[1] / (frames * world * args.steps) / code.K},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name, J, L, Z, snr, iters, y_block, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

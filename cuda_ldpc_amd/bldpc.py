@@ -45,6 +45,23 @@ def Transform_H(H, J, L, Z, Weight_Checknode, Weight_Variablenode, as_written=Fa
     return addr
 
 
+def AWGNChannel_CPU(seed, sigma, N, F, CodeWord=None):
+    """AWGNChannel_CPU (LDPC_Encoder.cu:25-43). seed: int32[3] numpy array, advanced in place (AWGN->seed).
+    Returns Channel_Out as a host float32 array [N, F] (frame-fastest)."""
+    if not (isinstance(seed, np.ndarray) and seed.dtype == np.int32 and seed.size == 3):
+        raise ValueError("seed must be an int32 numpy array of 3")
+    out = np.empty((N, F), np.float32)
+    cw = None if CodeWord is None else np.ascontiguousarray(CodeWord, np.int32)
+    check(lib.bldpc_awgn_channel_host(_np_ptr(seed), ctypes.c_float(sigma), _np_ptr(out), None if cw is None else _np_ptr(cw), N, F),
+          "AWGNChannel_CPU")
+    return out
+
+
+def sigma_of(SNR, snrtype=1, rate=0.0):
+    """sigma of a sweep point (main.cu:120-127); snrtype 1 = Es/N0 (the reference default, define.cuh:45)."""
+    return float(lib.bldpc_sigma(np.float32(SNR), snrtype, np.float32(rate)))
+
+
 class BinaryCode:
     """Device-resident code object (bldpc_code).  Build with from_blockh / from_shifts / from_table."""
 

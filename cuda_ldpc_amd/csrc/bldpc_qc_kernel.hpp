@@ -66,9 +66,19 @@ template <int NF> __device__ __forceinline__ void lds_st(float *lds, int idx, co
     *reinterpret_cast<typename Msg<NF>::T *>(lds + idx) = v;
 }
 
+// Packed pairs of 16-bit LDS slot indices (one slot = NF floats); halves the address registers.
+template <int NF> __device__ __forceinline__ int slot_lo(unsigned pk) { return (int)(pk & 0xffffu) * NF; }
+template <int NF> __device__ __forceinline__ int slot_hi(unsigned pk) { return (int)(pk >> 16) * NF; }
+
 // NF frames per lane, RPT check rows per thread (max), WC max row weight,
-// CPT variable columns per thread (max), WV max column weight, TPB threads per workgroup.
-template <int NF, int RPT, int WC, int CPT, int WV, int TPB>
+// CPT variable columns per thread (max), WV max column weight, TPB threads per workgroup,
+// HIST: record the per-iteration termination flags (flag history / batch-global exit).
+//
+// The iteration loop is branch-free below row/column granularity: rows lighter than WC are padded
+// with dummy edges that read a +inf slot (neutral for min1/min2/sign) and write into the row's own
+// padding blocks; columns lighter than WV read a slot that always holds +0.0f (adding +0.0f to a sum
+// that is never -0.0f is exact), so the compiler can keep all LDS reads of a phase in flight.
+template <int NF, int RPT, int WC, int CPT, int WV, int TPB, bool HIST>
 __global__ __launch_bounds__(TPB) void k_qc(QcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -83,161 +93,210 @@ __global__ __launch_bounds__(TPB) void k_qc(QcArgs a)
     const int g = __builtin_amdgcn_readfirstlane(tid / U); // wave-uniform (U % 64 == 0)
     const int u = tid - g * U;
     const int p = u / Z, t = u - p * Z;
-    const int f0 = (wg * FP + p) * NF;           // first frame carried by this lane
-    const int strideE = FP * Z * NF;             // floats between consecutive blocks / columns
-    const int lane_off = (p * Z + t) * NF;       // aligned position of this lane inside a block
-    const int Soff = a.nnz * strideE;
-    int *lds_flag = reinterpret_cast<int *>(lds + Soff + a.L * strideE); // [FP*NF]
+    const int f0 = (wg * FP + p) * NF;      // first frame carried by this lane
+    const int strideS = FP * Z;              // slots between consecutive blocks / columns
+    const int lane_slot = p * Z + t;         // aligned position of this lane inside a block
+    const int Sslot = a.J * WC * strideS;    // Rbuf: J rows x WC blocks (row-padded), then Sbuf: L columns
+    const int zero_slot = Sslot + a.L * strideS; // always +0.0f
+    const int inf_slot = zero_slot + 1;          // always +inf
+    const int trash_slot = inf_slot + 1;         // one block: S of padding columns (l >= L) lands here
+    int *lds_flag = reinterpret_cast<int *>(lds + (trash_slot + strideS) * NF); // [FP*NF]
 
     // ---- prologue: per-thread edge addresses, channel values, zeroed R ------------------
     float Rreg[RPT][WC][NF];
-    int saddr[RPT][WC];
-    int wrow[RPT], rbase[RPT];
+    unsigned saddr[RPT][(WC + 1) / 2];
+    int rbase[RPT];
+    bool rvalid[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
         const int j = g + rr * G;
-        wrow[rr] = 0;
-        rbase[rr] = 0;
-        if (j < a.J) {
-            const int e0 = a.rowptr[j];
-            wrow[rr] = a.rowptr[j + 1] - e0;
-            rbase[rr] = e0 * strideE + lane_off;
+        rvalid[rr] = j < a.J;
+        rbase[rr] = (j * WC * strideS + lane_slot) * NF;
+        const int e0 = rvalid[rr] ? a.rowptr[j] : 0;
+        const int w = rvalid[rr] ? a.rowptr[j + 1] - e0 : 0;
 #pragma unroll
-            for (int pp = 0; pp < WC; pp++) {
-                saddr[rr][pp] = 0;
+        for (int pp = 0; pp < WC; pp++) {
+            int slot = inf_slot;
+            if (pp < w) {
+                const QcCnEdge ed = a.cn_edges[e0 + pp];
+                int c = t + ed.shift;
+                c = (c >= Z) ? c - Z : c;
+                slot = Sslot + ed.col * strideS + p * Z + c;
+            }
+            if (pp & 1) saddr[rr][pp / 2] |= (unsigned)slot << 16;
+            else saddr[rr][pp / 2] = (unsigned)slot;
 #pragma unroll
-                for (int v = 0; v < NF; v++) Rreg[rr][pp][v] = 0.0f;
-                if (pp < wrow[rr]) {
-                    const QcCnEdge ed = a.cn_edges[e0 + pp];
-                    int c = t + ed.shift;
-                    c = (c >= Z) ? c - Z : c;
-                    saddr[rr][pp] = Soff + ed.col * strideE + (p * Z + c) * NF;
-                    const float zero[NF] = {};
-                    lds_st<NF>(lds, rbase[rr] + pp * strideE, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
-                }
+            for (int v = 0; v < NF; v++) Rreg[rr][pp][v] = 0.0f;
+            if (rvalid[rr]) {
+                const float zero[NF] = {};
+                lds_st<NF>(lds, rbase[rr] + pp * strideS * NF, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
             }
         }
     }
     float yreg[CPT][NF];
-    int raddr[CPT][WV];
-    int wcol[CPT];
+    unsigned raddr[CPT][(WV + 1) / 2];
+    bool cvalid[CPT];
+    int swrite[CPT]; // float index of this lane's S slot per column (trash block for padding columns)
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
         const int l = g + cc * G;
-        wcol[cc] = 0;
+        cvalid[cc] = l < a.L;
+        const int w = cvalid[cc] ? a.wv[l] : 0;
+        swrite[cc] = ((cvalid[cc] ? Sslot + l * strideS : trash_slot) + lane_slot) * NF;
 #pragma unroll
-        for (int v = 0; v < NF; v++) yreg[cc][v] = 0.0f;
-        if (l < a.L) {
-            wcol[cc] = a.wv[l];
-#pragma unroll
-            for (int k = 0; k < WV; k++) {
-                raddr[cc][k] = 0;
-                if (k < wcol[cc]) {
-                    const QcVnEdge ed = a.vn_edges[l * WV + k];
-                    int r = t - ed.shift;
-                    r = (r < 0) ? r + Z : r;
-                    raddr[cc][k] = ed.e * strideE + (p * Z + r) * NF;
-                }
+        for (int k = 0; k < WV; k++) {
+            int slot = zero_slot;
+            if (k < w) {
+                const QcVnEdge ed = a.vn_edges[l * WV + k]; // ed.e = row * WC + position
+                int r = t - ed.shift;
+                r = (r < 0) ? r + Z : r;
+                slot = ed.e * strideS + p * Z + r;
             }
-#pragma unroll
-            for (int v = 0; v < NF; v++)
-                if (f0 + v < F) yreg[cc][v] = a.y[(size_t)(l * Z + t) * F + f0 + v];
+            if (k & 1) raddr[cc][k / 2] |= (unsigned)slot << 16;
+            else raddr[cc][k / 2] = (unsigned)slot;
         }
+#pragma unroll
+        for (int v = 0; v < NF; v++) {
+            yreg[cc][v] = 0.0f;
+            if (cvalid[cc] && f0 + v < F) yreg[cc][v] = a.y[(size_t)(l * Z + t) * F + f0 + v];
+        }
+    }
+    if (tid < NF) {
+        lds[zero_slot * NF + tid] = 0.0f;
+        lds[inf_slot * NF + tid] = __builtin_inff();
     }
     if (tid < FP * NF) lds_flag[tid] = 0;
     unsigned long long hist = 0; // used by threads tid < FP*NF
     __syncthreads();
 
-    // ---- iterations ------------------------------------------------------------------------
-    for (int it = 1; it <= a.max_iter; it++) {
-        const bool last = (it == a.max_iter);
-        // VN phase (LDPC_Decoder.cu:188-210)
+    // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
+    auto vn_phase = [&](bool (&bad)[NF]) {
+        float R[CPT][WV][NF];
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+#pragma unroll
+            for (int k = 0; k < WV; k++)
+                lds_ld<NF>(R[cc][k], lds, (k & 1) ? slot_hi<NF>(raddr[cc][k / 2]) : slot_lo<NF>(raddr[cc][k / 2]));
+        }
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            float S[NF];
+#pragma unroll
+            for (int v = 0; v < NF; v++) S[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < WV; k++) {
+#pragma unroll
+                for (int v = 0; v < NF; v++) S[v] += R[cc][k][v];
+            }
+#pragma unroll
+            for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
+            lds_st<NF>(lds, swrite[cc], S);
+            if (HIST) {
+                const bool in_len = cvalid[cc] && ((g + cc * G) * Z + t) < a.length;
+#pragma unroll
+                for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
+            }
+        }
+    };
+
+    // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147); call between VN phase and barrier / after it
+    auto flags_publish = [&](const bool (&bad)[NF]) {
+#pragma unroll
+        for (int v = 0; v < NF; v++)
+            if (bad[v]) lds_flag[p * NF + v] = 1; // same value from every writer
+    };
+    auto flags_collect = [&](int it) -> int {
+        int flag = 0;
+        if (tid < FP * NF) {
+            flag = lds_flag[tid] ? 0 : 1;
+            lds_flag[tid] = 0;
+            if (flag && it <= 64) hist |= (1ull << (it - 1));
+        }
+        return flag;
+    };
+
+    // ---- iterations 1 .. max_iter-1: VN, CN ----------------------------------------------
+    for (int it = 1; it < a.max_iter; it++) {
+        // keep the 16-bit-packed slot indices packed across iterations (the unpacked form costs 2x the VGPRs)
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+            for (int i = 0; i < (WC + 1) / 2; i++) asm volatile("" : "+v"(saddr[rr][i]));
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++)
+#pragma unroll
+            for (int i = 0; i < (WV + 1) / 2; i++) asm volatile("" : "+v"(raddr[cc][i]));
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int l = g + cc * G;
-            if (l < a.L) {
-                float S[NF];
-#pragma unroll
-                for (int v = 0; v < NF; v++) S[v] = 0.0f;
-#pragma unroll
-                for (int k = 0; k < WV; k++)
-                    if (k < wcol[cc]) {
-                        float R[NF];
-                        lds_ld<NF>(R, lds, raddr[cc][k]);
-#pragma unroll
-                        for (int v = 0; v < NF; v++) S[v] += R[v];
-                    }
-#pragma unroll
-                for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
-                lds_st<NF>(lds, Soff + l * strideE + lane_off, S);
-                const int n = l * Z + t;
-                if (n < a.length) {
-#pragma unroll
-                    for (int v = 0; v < NF; v++) bad[v] = bad[v] || (S[v] < 0);
-                }
-                if (last) {
-#pragma unroll
-                    for (int v = 0; v < NF; v++)
-                        if (f0 + v < F) {
-                            a.D[(size_t)n * F + f0 + v] = (S[v] < 0) ? 1 : 0;
-                            if (a.app) a.app[(size_t)n * F + f0 + v] = S[v];
-                        }
-                }
-            }
-        }
-        if (a.hist || last) {
-#pragma unroll
-            for (int v = 0; v < NF; v++)
-                if (bad[v]) lds_flag[p * NF + v] = 1; // same value from every writer
-        }
+        vn_phase(bad);
+        if (HIST) flags_publish(bad);
         __syncthreads();
-        if ((a.hist || last) && tid < FP * NF) {
-            const int flag = lds_flag[tid] ? 0 : 1; // LDPC_Decoder.cu:137-147
-            lds_flag[tid] = 0;
-            if (flag && it <= 64) hist |= (1ull << (it - 1));
-            const int f = wg * FP * NF + tid;
-            if (last && f < F) {
-                a.D[(size_t)a.L * Z * F + f] = flag;
-                if (a.hist) a.hist[f] = hist;
-            }
-        }
-        if (last) break; // the CN pass after the final VN pass is unobservable
+        if (HIST) (void)flags_collect(it);
 
         // CN phase (LDPC_Decoder.cu:279-314)
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
-            if (g + rr * G < a.J) {
+            if (rvalid[rr]) {
                 float Q[WC][NF];
+#pragma unroll
+                for (int pp = 0; pp < WC; pp++)
+                    lds_ld<NF>(Q[pp], lds, (pp & 1) ? slot_hi<NF>(saddr[rr][pp / 2]) : slot_lo<NF>(saddr[rr][pp / 2]));
                 CnAcc acc[NF];
 #pragma unroll
                 for (int v = 0; v < NF; v++) acc[v].init();
 #pragma unroll
-                for (int pp = 0; pp < WC; pp++)
-                    if (pp < wrow[rr]) {
-                        float S[NF];
-                        lds_ld<NF>(S, lds, saddr[rr][pp]);
+                for (int pp = 0; pp < WC; pp++) {
 #pragma unroll
-                        for (int v = 0; v < NF; v++) {
-                            Q[pp][v] = S[v] - Rreg[rr][pp][v];
-                            acc[v].add(Q[pp][v]);
-                        }
+                    for (int v = 0; v < NF; v++) {
+                        Q[pp][v] = Q[pp][v] - Rreg[rr][pp][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
+                        acc[v].add(Q[pp][v]);
                     }
+                }
                 uint32_t key[NF];
 #pragma unroll
                 for (int v = 0; v < NF; v++) key[v] = acc[v].key();
 #pragma unroll
-                for (int pp = 0; pp < WC; pp++)
-                    if (pp < wrow[rr]) {
+                for (int pp = 0; pp < WC; pp++) {
 #pragma unroll
-                        for (int v = 0; v < NF; v++) Rreg[rr][pp][v] = cn_out(Q[pp][v], acc[v].m2, key[v]);
-                        lds_st<NF>(lds, rbase[rr] + pp * strideE, Rreg[rr][pp]);
-                    }
+                    for (int v = 0; v < NF; v++) Rreg[rr][pp][v] = cn_out(Q[pp][v], acc[v].m2, key[v]);
+                    lds_st<NF>(lds, rbase[rr] + pp * strideS * NF, Rreg[rr][pp]);
+                }
             }
         }
         __syncthreads();
+    }
+
+    // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -------
+    {
+        bool bad[NF];
+#pragma unroll
+        for (int v = 0; v < NF; v++) bad[v] = false;
+        vn_phase(bad);
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            if (cvalid[cc]) {
+                const int n = (g + cc * G) * Z + t;
+                float S[NF];
+                lds_ld<NF>(S, lds, swrite[cc]); // own value, just written
+#pragma unroll
+                for (int v = 0; v < NF; v++) {
+                    if (!HIST) bad[v] = bad[v] || (n < a.length && S[v] < 0);
+                    if (f0 + v < F) {
+                        a.D[(size_t)n * F + f0 + v] = (S[v] < 0) ? 1 : 0;
+                        if (a.app) a.app[(size_t)n * F + f0 + v] = S[v];
+                    }
+                }
+            }
+        }
+        flags_publish(bad);
+        __syncthreads();
+        const int flag = flags_collect(a.max_iter);
+        const int f = wg * FP * NF + tid;
+        if (tid < FP * NF && f < F) {
+            a.D[(size_t)a.L * Z * F + f] = flag;
+            if (HIST && a.hist) a.hist[f] = hist;
+        }
     }
 }
 
@@ -264,7 +323,7 @@ struct QcPlan {
 };
 
 using QcKernel = void (*)(QcArgs);
-struct QcVariant { int NF, RPT, WC, CPT, WV, TPB; QcKernel fn; };
+struct QcVariant { int NF, RPT, WC, CPT, WV, TPB; QcKernel fn, fn_hist; };
 
 // Ahead-of-time instantiations.  A code runs on the first variant whose bounds
 // cover it; codes outside all of them use the table kernels.
@@ -279,7 +338,7 @@ struct QcVariant { int NF, RPT, WC, CPT, WV, TPB; QcKernel fn; };
 
 inline const QcVariant *qc_variants(int *count)
 {
-#define X(NF, RPT, WC, CPT, WV, TPB) {NF, RPT, WC, CPT, WV, TPB, k_qc<NF, RPT, WC, CPT, WV, TPB>},
+#define X(NF, RPT, WC, CPT, WV, TPB) {NF, RPT, WC, CPT, WV, TPB, k_qc<NF, RPT, WC, CPT, WV, TPB, false>, k_qc<NF, RPT, WC, CPT, WV, TPB, true>},
     static const QcVariant v[] = {QC_VARIANTS(X)};
 #undef X
     *count = (int)(sizeof(v) / sizeof(v[0]));
@@ -328,19 +387,20 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     const QcVariant *vars = qc_variants(&nvar);
     for (int NF = 2; NF >= 1 && q->frames_per_wg == 0; NF--) {
         const int FP = FPmin, U = FP * Z;
-        const size_t lds = ((size_t)(nnz + L) * U * NF + FP * NF) * sizeof(float);
-        if (lds > kLdsBytes || U > 1024) continue;
+        if (U > 1024) continue;
         for (int vi = 0; vi < nvar && q->frames_per_wg == 0; vi++) {
             const QcVariant &v = vars[vi];
             if (v.NF != NF || v.WC < Wc || v.WV < Wv) continue;
-            // largest group count the variant's thread budget allows, smallest that meets RPT/CPT
-            for (int G = std::min(v.TPB / U, std::max(J, 1)); G >= 1; G--) {
-                const int RPT = (J + G - 1) / G, CPT = (L + G - 1) / G;
-                if (RPT > v.RPT || CPT > v.CPT) break;
-                q->NF = NF; q->FP = FP; q->U = U; q->G = G; q->RPT = RPT; q->CPT = CPT;
-                q->threads = G * U; q->variant = vi; q->lds_bytes = lds; q->frames_per_wg = NF * FP;
-                break;
-            }
+            // LDS: R blocks (J rows padded to the variant's WC), S columns, the +0 / +inf slots, the flags
+            const size_t slots = (size_t)(J * v.WC + L + 1) * U + 2; // + one trash block
+            const size_t lds = (slots * NF + FP * NF) * sizeof(float);
+            if (lds > kLdsBytes || slots > 65535) continue; // slot indices are packed into 16 bits
+            const int G = std::min(v.TPB / U, std::max(J, 1));
+            if (G < 1) continue;
+            const int RPT = (J + G - 1) / G, CPT = (L + G - 1) / G;
+            if (RPT > v.RPT || CPT > v.CPT) continue;
+            q->NF = NF; q->FP = FP; q->U = U; q->G = G; q->RPT = RPT; q->CPT = CPT;
+            q->threads = G * U; q->variant = vi; q->lds_bytes = lds; q->frames_per_wg = NF * FP;
         }
     }
     if (q->frames_per_wg == 0) return BLDPC_OK;
@@ -350,7 +410,8 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     for (int j = 0; j < J; j++)
         for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
             const int l = cn[e].col;
-            vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)e, cn[e].shift}; // ascending j = the reference's edge order
+            // ascending j = the reference's edge order; .e = padded block index row*WC + position
+            vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift};
         }
     std::vector<unsigned char> wvb(L);
     for (int l = 0; l < L; l++) wvb[l] = (unsigned char)wv[l];
@@ -363,6 +424,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     CLDPC_HIP(hipMemcpy(q->d_vn, vn.data(), vn.size() * sizeof(QcVnEdge), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipMemcpy(q->d_wv, wvb.data(), wvb.size(), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes), BLDPC_EHIP);
+    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes), BLDPC_EHIP);
     snprintf(q->name, sizeof(q->name), "qc_lds<nf%d,rpt%d,wc%d,cpt%d,wv%d>g%d_fp%d_t%d", v.NF, v.RPT, v.WC, v.CPT, v.WV, q->G, q->FP,
              q->threads);
     return BLDPC_OK;
@@ -380,7 +442,7 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
     a.max_iter = max_iter; a.length = length; a.nnz = q->nnz;
     const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
-    hipLaunchKernelGGL(v.fn, dim3(grid), dim3(q->threads), q->lds_bytes, st, a);
+    hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(q->threads), q->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
 }

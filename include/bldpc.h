@@ -114,6 +114,16 @@ int bldpc_decode(bldpc_code *code, const float *Channel_Out, int F, int max_iter
 int bldpc_statistic(const bldpc_code *code, const int *D, const int *CodeWord, int F, int length, int iteraTime,
                     long long *counters, void *stream);
 
+/* Host input generator, bit-identical to the reference's (the "identical AWGN inputs" of the parity
+ * contract): AWGNChannel_CPU + RandomModule (LDPC_Encoder.cu:25-56).  seed[3] is advanced in place
+ * (AWGNChannel.seed, struct.cuh:13), sigma as main.cu:120-127 computes it (bldpc_sigma below).
+ * Channel_Out: HOST float [N][F], frame-outer / bit-inner draw order; CodeWord: host int32 [N][F] or
+ * NULL for the all-zero codeword. */
+int bldpc_awgn_channel_host(int seed[3], float sigma, float *Channel_Out, const int *CodeWord, int N, int F);
+
+/* sigma of the sweep point (main.cu:120-127): snrtype 0 = Eb/N0 (uses rate), 1 = Es/N0. */
+float bldpc_sigma(float SNR, int snrtype, float rate);
+
 /* Name of the kernel variant the last bldpc_decode on this code used (static string). */
 const char *bldpc_last_kernel(const bldpc_code *code);
 
