@@ -1,0 +1,273 @@
+// nbldpc_api.hip -- host side of the GF(q) EMS decoder behind include/nbldpc.h.
+//
+// Readers restate myNBLDPC/src/Simulation.cpp:347-467 (Get_H) and src/GF.cpp:68-117 (GFInitial);
+// nbldpc_ems_decode_batch replaces Decoding_EMS / Decoding_EMS_GPU (src/LDPC_Decoder.cpp:172-317,
+// src/Decode_GPU.cu:138-356) for a batch of frames; the channel helpers restate
+// src/LDPC_Encoder.cpp:41-79 and src/main.cu:203-228.
+#include "../../include/nbldpc.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "nbldpc_kernel.hpp"
+
+using namespace cldpc;
+
+struct nbldpc_code {
+    int N = 0, M = 0, q = 0, m = 0, dv = 0, dc = 0;
+    int *d_vn_w = nullptr, *d_vn_thr = nullptr, *d_vn_gf = nullptr;
+    int *d_cn_w = nullptr, *d_cn_src = nullptr, *d_cn_gf = nullptr, *d_cn_vn = nullptr;
+    unsigned char *d_mul = nullptr;
+    size_t lds_bytes = 0;
+};
+
+extern "C" const char *nbldpc_last_error(void) { return err_buf(); }
+
+extern "C" int nbldpc_read_matrix(const char *path, int dims[5], int *vn_w, int *vn_cn, int *vn_gf, int *cn_w, int *cn_vn, int *cn_gf)
+{
+    if (!path || !dims) return fail(NBLDPC_EINVAL, "nbldpc_read_matrix: null argument");
+    FILE *fp = fopen(path, "r");
+    if (!fp) return fail(NBLDPC_EIO, "can not open file: %s", path);
+    int N, M, q, dv, dc, v;
+    if (fscanf(fp, "%d %d %d %d %d", &N, &M, &q, &dv, &dc) != 5 || N <= 0 || M <= 0 || q < 2 || dv <= 0 || dc <= 0) {
+        fclose(fp);
+        return fail(NBLDPC_EIO, "%s: bad header", path);
+    }
+    dims[0] = N; dims[1] = M; dims[2] = q; dims[3] = dv; dims[4] = dc;
+    if (!vn_w) { fclose(fp); return NBLDPC_OK; }
+    if (!vn_cn || !vn_gf || !cn_w || !cn_vn || !cn_gf) { fclose(fp); return fail(NBLDPC_EINVAL, "nbldpc_read_matrix: null array"); }
+    auto bad = [&](const char *what) { fclose(fp); return fail(NBLDPC_EIO, "%s: %s", path, what); };
+    for (int i = 0; i < N; i++)
+        if (fscanf(fp, "%d", &vn_w[i]) != 1 || vn_w[i] < 0 || vn_w[i] > dv) return bad("bad column weight");
+    for (int i = 0; i < M; i++)
+        if (fscanf(fp, "%d", &cn_w[i]) != 1 || cn_w[i] < 0 || cn_w[i] > dc) return bad("bad row weight");
+    for (int i = 0; i < N * dv; i++) { vn_cn[i] = -1; vn_gf[i] = 0; }
+    for (int i = 0; i < M * dc; i++) { cn_vn[i] = -1; cn_gf[i] = 0; }
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < vn_w[i]; j++) {
+            if (fscanf(fp, "%d", &v) != 1 || v < 1 || v > M) return bad("bad check index");
+            vn_cn[i * dv + j] = v - 1;
+            if (fscanf(fp, "%d", &v) != 1 || v < 0 || v >= q) return bad("bad field element");
+            vn_gf[i * dv + j] = v;
+        }
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < cn_w[i]; j++) {
+            if (fscanf(fp, "%d", &v) != 1 || v < 1 || v > N) return bad("bad variable index");
+            cn_vn[i * dc + j] = v - 1;
+            if (fscanf(fp, "%d", &v) != 1 || v < 0 || v >= q) return bad("bad field element");
+            cn_gf[i * dc + j] = v;
+        }
+    fclose(fp);
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_gf_load(const char *path, int q, unsigned *mul, unsigned *add, unsigned *inv)
+{
+    if (!path || !mul || !add || !inv || q < 2) return fail(NBLDPC_EINVAL, "nbldpc_gf_load: bad argument");
+    FILE *fp = fopen(path, "r");
+    if (!fp) return fail(NBLDPC_EIO, "Cannot open %s", path);
+    char word[256];
+    int c;
+    bool ok = true;
+    while ((c = fgetc(fp)) != EOF && c != '\n') {} // title line (GF.cpp:90)
+    ok = ok && fscanf(fp, "%255s %255s", word, word) == 2;
+    for (int i = 0; ok && i < q * q; i++) ok = fscanf(fp, "%u", &mul[i]) == 1;
+    ok = ok && fscanf(fp, "%255s %255s", word, word) == 2;
+    for (int i = 0; ok && i < q * q; i++) ok = fscanf(fp, "%u", &add[i]) == 1;
+    ok = ok && fscanf(fp, "%255s %255s", word, word) == 2;
+    for (int i = 0; ok && i < q; i++) ok = fscanf(fp, "%u", &inv[i]) == 1;
+    fclose(fp);
+    return ok ? NBLDPC_OK : fail(NBLDPC_EIO, "%s: truncated GF(%d) table file", path, q);
+}
+
+extern "C" int nbldpc_gf_generate(int q, unsigned poly, unsigned *mul, unsigned *add, unsigned *inv)
+{
+    int m = 0;
+    while ((1 << m) < q) m++;
+    if (q < 2 || (1 << m) != q || q > 4096 || !mul || !add || !inv) return fail(NBLDPC_EINVAL, "nbldpc_gf_generate: q=%d must be 2^m", q);
+    if ((poly >> m) != 1u) return fail(NBLDPC_EINVAL, "primitive polynomial %u does not have degree %d", poly, m);
+    for (int a = 0; a < q; a++)
+        for (int b = 0; b < q; b++) {
+            unsigned r = 0, x = (unsigned)a;
+            for (int i = 0; i < m; i++) { // carry-less multiply, reduced on the fly
+                if ((b >> i) & 1) r ^= x;
+                x <<= 1;
+                if (x & (unsigned)q) x ^= poly;
+            }
+            mul[a * q + b] = r;
+            add[a * q + b] = (unsigned)(a ^ b);
+        }
+    inv[0] = 0; // GF/Arith.Table: inv[0] = 0
+    for (int a = 1; a < q; a++) {
+        inv[a] = 0;
+        for (int b = 1; b < q; b++)
+            if (mul[a * q + b] == 1) { inv[a] = (unsigned)b; break; }
+        if (!inv[a]) return fail(NBLDPC_EINVAL, "polynomial %u is not irreducible over GF(2): %d has no inverse", poly, a);
+    }
+    return NBLDPC_OK;
+}
+
+static int up(void **dst, const void *src, size_t bytes)
+{
+    CLDPC_HIP(hipMalloc(dst, bytes), NBLDPC_ENOMEM);
+    CLDPC_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), NBLDPC_EHIP);
+    return NBLDPC_OK;
+}
+
+static size_t nb_lds_bytes(int N, int M, int q, int dv, int dc)
+{
+    return ((size_t)N * dv * nb_pair_stride(q) + (size_t)q * M * dc + N + 4) * sizeof(float) + (size_t)q * q;
+}
+
+extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int *vn_w, const int *vn_cn, const int *vn_gf,
+                                  const int *cn_w, const int *cn_vn, const int *cn_gf, const unsigned *mul, nbldpc_code **out)
+{
+    if (!vn_w || !vn_cn || !vn_gf || !cn_w || !cn_vn || !cn_gf || !mul || !out) return fail(NBLDPC_EINVAL, "nbldpc_code_create: null argument");
+    int m = 0;
+    while ((1 << m) < q) m++;
+    if (N <= 0 || M <= 0 || q < 4 || (1 << m) != q) return fail(NBLDPC_EINVAL, "bad dimensions N=%d M=%d q=%d", N, M, q);
+    if (q != 16 && q != 32 && q != 64) return fail(NBLDPC_EUNSUPPORTED, "fused EMS kernel supports q in {16,32,64} (got %d)", q);
+    if (dv > kNbMaxDv || dc > kNbMaxW) return fail(NBLDPC_EUNSUPPORTED, "dvmax=%d (<= %d) / dcmax=%d (<= %d) unsupported", dv, kNbMaxDv, dc, kNbMaxW);
+    if (M * dc > kNbThreads || M > kNbThreads) return fail(NBLDPC_EUNSUPPORTED, "M*dcmax = %d exceeds %d check-edge threads per frame", M * dc, kNbThreads);
+    const size_t lds = nb_lds_bytes(N, M, q, dv, dc);
+    if (lds > 160 * 1024) return fail(NBLDPC_EUNSUPPORTED, "per-frame message state %zu B exceeds the 160 KiB LDS of one CU", lds);
+    // cross indices: index_in_CN / index_in_VN (LDPC_Decoder.cpp:106-130), first match
+    std::vector<int> vn_thr((size_t)N * dv, 0), cn_src((size_t)M * dc, 0);
+    for (int i = 0; i < N; i++)
+        for (int d = 0; d < vn_w[i]; d++) {
+            const int cn = vn_cn[i * dv + d];
+            if (cn < 0 || cn >= M) return fail(NBLDPC_EINVAL, "VN %d edge %d: check index %d out of range", i, d, cn);
+            int slot = -1;
+            for (int t = 0; t < cn_w[cn]; t++)
+                if (cn_vn[cn * dc + t] == i) { slot = t; break; }
+            if (slot < 0) return fail(NBLDPC_EINVAL, "index_in_CN error: VN %d not listed by CN %d", i, cn);
+            if (vn_gf[i * dv + d] <= 0 || vn_gf[i * dv + d] >= q) return fail(NBLDPC_EINVAL, "VN %d edge %d: coefficient %d", i, d, vn_gf[i * dv + d]);
+            vn_thr[i * dv + d] = cn * dc + slot;
+        }
+    for (int r = 0; r < M; r++) {
+        if (cn_w[r] < 2 || cn_w[r] > dc) return fail(NBLDPC_EUNSUPPORTED, "row %d weight %d outside [2,%d]", r, cn_w[r], dc);
+        for (int t = 0; t < cn_w[r]; t++) {
+            const int vn = cn_vn[r * dc + t];
+            if (vn < 0 || vn >= N) return fail(NBLDPC_EINVAL, "CN %d slot %d: variable index %d out of range", r, t, vn);
+            int idx = -1;
+            for (int d = 0; d < vn_w[vn]; d++)
+                if (vn_cn[vn * dv + d] == r) { idx = d; break; }
+            if (idx < 0) return fail(NBLDPC_EINVAL, "index_in_VN error: CN %d not listed by VN %d", r, vn);
+            if (cn_gf[r * dc + t] != vn_gf[vn * dv + idx]) return fail(NBLDPC_EINVAL, "CN %d slot %d: coefficient differs between the two views", r, t);
+            cn_src[r * dc + t] = vn * dv + idx;
+        }
+    }
+    std::vector<unsigned char> mulb((size_t)q * q);
+    for (int i = 0; i < q * q; i++) {
+        if (mul[i] >= (unsigned)q) return fail(NBLDPC_EINVAL, "TableMultiply[%d] = %u outside GF(%d)", i, mul[i], q);
+        mulb[i] = (unsigned char)mul[i];
+    }
+    nbldpc_code *c = new (std::nothrow) nbldpc_code;
+    if (!c) return fail(NBLDPC_ENOMEM, "out of host memory");
+    c->N = N; c->M = M; c->q = q; c->m = m; c->dv = dv; c->dc = dc; c->lds_bytes = lds;
+    int r = 0;
+    if (!r) r = up((void **)&c->d_vn_w, vn_w, (size_t)N * sizeof(int));
+    if (!r) r = up((void **)&c->d_vn_thr, vn_thr.data(), vn_thr.size() * sizeof(int));
+    if (!r) r = up((void **)&c->d_vn_gf, vn_gf, (size_t)N * dv * sizeof(int));
+    if (!r) r = up((void **)&c->d_cn_w, cn_w, (size_t)M * sizeof(int));
+    if (!r) r = up((void **)&c->d_cn_src, cn_src.data(), cn_src.size() * sizeof(int));
+    if (!r) r = up((void **)&c->d_cn_gf, cn_gf, (size_t)M * dc * sizeof(int));
+    if (!r) r = up((void **)&c->d_cn_vn, cn_vn, (size_t)M * dc * sizeof(int));
+    if (!r) r = up((void **)&c->d_mul, mulb.data(), mulb.size());
+    if (!r) {
+        hipError_t e = hipSuccess;
+        if (q == 64) e = hipFuncSetAttribute((const void *)k_nb_ems<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (q == 32) e = hipFuncSetAttribute((const void *)k_nb_ems<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (q == 16) e = hipFuncSetAttribute((const void *)k_nb_ems<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    if (r) { nbldpc_code_destroy(c); return r; }
+    *out = c;
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_code_destroy(nbldpc_code *c)
+{
+    if (!c) return NBLDPC_OK;
+    void *ptrs[] = {c->d_vn_w, c->d_vn_thr, c->d_vn_gf, c->d_cn_w, c->d_cn_src, c->d_cn_gf, c->d_cn_vn, c->d_mul};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete c;
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, int Nm, int Nc, int maxIT, int maxdc_cfg, int *out,
+                                       int *iters, int *ok, float *LLR, float *c2v, void *stream)
+{
+    if (!c || !Lch || !out || !iters || !ok) return fail(NBLDPC_EINVAL, "nbldpc_ems_decode_batch: null argument");
+    if (B <= 0 || maxIT <= 0) return fail(NBLDPC_EINVAL, "B=%d maxIT=%d must be positive", B, maxIT);
+    if (Nm < 1 || Nm > c->q || Nc < 0) return fail(NBLDPC_EINVAL, "EMS_Nm=%d must be in [1,%d], EMS_Nc=%d >= 0", Nm, c->q, Nc);
+    NbArgs a;
+    a.Lch = Lch; a.out = out; a.iters = iters; a.ok = ok; a.LLR = LLR; a.c2v = c2v;
+    a.vn_w = c->d_vn_w; a.vn_thr = c->d_vn_thr; a.vn_gf = c->d_vn_gf;
+    a.cn_w = c->d_cn_w; a.cn_src = c->d_cn_src; a.cn_gf = c->d_cn_gf; a.cn_vn = c->d_cn_vn; a.mul = c->d_mul;
+    a.N = c->N; a.M = c->M; a.q = c->q; a.dv = c->dv; a.dc = c->dc; a.B = B; a.Nm = Nm; a.Nc = Nc; a.max_iter = maxIT;
+    a.dcmax_cfg = maxdc_cfg > 0 ? maxdc_cfg : c->dc;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->q == 64) hipLaunchKernelGGL(k_nb_ems<64>, dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
+    else if (c->q == 32) hipLaunchKernelGGL(k_nb_ems<32>, dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_nb_ems<16>, dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_demodulate_bpsk(const nbldpc_code *c, const float *rx, float sigma, int B, float *Lch, void *stream)
+{
+    if (!c || !rx || !Lch || B <= 0 || !(sigma > 0)) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_bpsk: bad argument");
+    const size_t total = (size_t)B * c->N * (c->q - 1);
+    hipLaunchKernelGGL(k_nb_demod_bpsk, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rx, sigma, B, c->N, c->q,
+                       c->m, Lch);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_statistic(const nbldpc_code *c, const int *out, const int *iters, const int *ok, const int *cw, int B,
+                                long long *counters, void *stream)
+{
+    if (!c || !out || !iters || !ok || !cw || !counters || B <= 0) return fail(NBLDPC_EINVAL, "nbldpc_statistic: bad argument");
+    hipLaunchKernelGGL(k_nb_statistic, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, iters, ok, cw, B, c->N, counters);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    return NBLDPC_OK;
+}
+
+namespace {
+inline float random_module(int *seed) // src/LDPC_Encoder.cpp:70-79
+{
+    seed[0] = (seed[0] * 249) % 61967;
+    seed[1] = (seed[1] * 251) % 63443;
+    seed[2] = (seed[2] * 252) % 63599;
+    float t = ((float)seed[0] / 61967.0f) + ((float)seed[1] / 63443.0f) + ((float)seed[2] / 63599.0f);
+    t -= (int)t;
+    return t;
+}
+} // namespace
+
+extern "C" int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *cw, int N, int m, float *rx)
+{
+    if (!seed || !cw || !rx || N <= 0 || m <= 0) return fail(NBLDPC_EINVAL, "nbldpc_awgn_channel_host: bad argument");
+    const double two_pi = 2 * 3.1415926; // define.h:56
+    for (int i = 0; i < N * m; i++) {
+        const float tx = ((cw[i / m] >> (i % m)) & 1) ? -1.0f : 1.0f; // main.cu:203-209 + Constellation/BPSK.txt
+        float u1 = random_module(seed), u2 = random_module(seed);
+        const float amp = std::sqrt(-2.0f * std::log(1.0f - u1));
+        rx[i] = (float)((double)sigma * std::cos(two_pi * (double)u2) * (double)amp + (double)tx);
+        (void)random_module(seed); // the Image part draws two more numbers (LDPC_Encoder.cpp:62-66)
+        (void)random_module(seed);
+    }
+    return NBLDPC_OK;
+}
+
+extern "C" float nbldpc_sigma(float snr, int snrtype, int n_qam, float rate)
+{
+    if (snrtype == 0) return (float)std::sqrt(0.5 / (std::log((double)n_qam) / std::log(2.0) * rate * std::pow(10.0, (double)(snr / 10.0))));
+    return (float)std::sqrt(0.5 / (std::log((double)n_qam) / std::log(2.0) * std::pow(10.0, (double)(snr / 10.0))));
+}

@@ -1,0 +1,360 @@
+// nbldpc_kernel.hpp -- fused GF(q) EMS decoder: one workgroup = one frame, all iterations on-chip.
+//
+// Bit-exact restatement of the reference's CPU decoder (myNBLDPC/src/LDPC_Decoder.cpp:172-359), whose
+// float operation order is the canonical one: the configuration-set walk of ConstructConf
+// carries its running sum by reference, so `s + v ... s - v` rounding drift must be replayed in the
+// reference's depth-first order.  That order does not depend on the data, so each (check row, edge)
+// thread executes a fixed straight-line program over its neighbours' sorted messages.
+//
+// LDS (one frame):   pairs[NE][q] (float value, int premultiplied symbol), padded per edge against
+//                    bank conflicts;  E[q][TC] the per-(row,edge) max arrays (EMS_L_c2v), thread-fastest
+//                    so that each lane owns one bank;  the GF multiplication table as bytes.
+// Phases per iteration (LDPC_Decoder.cpp:199-313):
+//   A  one wave per variable node, lane k <-> vector element k: c2v from E (the double division of
+//      :309), LLR = L_ch + sum c2v (:202-214), hard decision (:71-91), v2c = LLR - c2v (:241-251)
+//   S  syndrome over GF(q) (:218-238); a frame leaves as soon as it is zero
+//   B  one wave per edge: stable descending sort (:17-36,253-269) by rank = #greater + #equal-before
+//   C  one thread per (row, edge): conf(q,1) then conf(Nm,Nc) (:272-303, :319-359) into E
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cldpc {
+
+constexpr int kNbThreads = 512;
+constexpr int kNbMaxDv = 8;
+constexpr int kNbMaxW = 6; // row weights handled by the templated walk
+
+struct NbArgs {
+    const float *Lch; // [B][N][q-1]
+    int *out;         // [B][N]
+    int *iters;       // [B]
+    int *ok;          // [B]
+    float *LLR;       // [B][N][q-1] or nullptr
+    float *c2v;       // [B][M][dc][q-1] or nullptr
+    const int *vn_w;   // [N]
+    const int *vn_thr; // [N][dv]  CN thread (row*dc + slot) at the other end of each VN edge
+    const int *vn_gf;  // [N][dv]
+    const int *cn_w;   // [M]
+    const int *cn_src; // [M][dc]  VN edge (vn*dv + idx) at the other end of each CN slot
+    const int *cn_gf;  // [M][dc]
+    const int *cn_vn;  // [M][dc]
+    const unsigned char *mul; // [q][q]
+    int N, M, q, dv, dc, B, Nm, Nc, max_iter, dcmax_cfg;
+};
+
+__host__ __device__ inline int nb_pair_stride(int q) { return 2 * q + 2; } // floats per edge (+2: bank skew)
+
+__device__ __forceinline__ float nb_wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <int NACT> struct NbCn {
+    int pb[NACT];                   // float index of each active neighbour's sorted pairs
+    float v0[NACT], v1[NACT];       // its two largest values   (sort_L_v2c[..][0..1])
+    int m0[NACT], m1[NACT];         // and their premultiplied symbols
+    float s;                        // sumNonLLR, carried by reference through the walk
+    float *E;                       // &E[0*TC + thr]
+    const float *pairs;
+    int TC;
+};
+
+// Sub-walk entered with diff == 1 (one deviation already spent) at depth D: exactly one leaf (all
+// remaining positions at k = 0), then on the way back every position tries k = 1, exceeds Nc = 1
+// and is undone (LDPC_Decoder.cpp:347-354).  Returns the leaf (sum, symbol); c.s keeps the drift.
+template <int D, int NACT> __device__ __forceinline__ void nb_t1(NbCn<NACT> &c, int symbase, float &sLeaf, int &symLeaf)
+{
+    float s = c.s;
+    int sym = symbase;
+#pragma unroll
+    for (int d = D; d < NACT; d++) {
+        s = s + c.v0[d];
+        sym ^= c.m0[d];
+    }
+    sLeaf = s;
+    symLeaf = sym;
+#pragma unroll
+    for (int d = NACT - 1; d >= D; d--) {
+        s = s - c.v0[d];
+        s = s + c.v1[d];
+        s = s - c.v1[d];
+    }
+    c.s = s;
+}
+
+// conf(q, 1) entered with diff == 0 at depth D (LDPC_Decoder.cpp:286 via :319-359).
+// CH = leaves batched per LDS round trip (their symbols are pairwise distinct inside one k-loop,
+// because the sorted symbol list is a permutation and multiplication by h != 0 is a bijection).
+template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NACT> &c, int symbase)
+{
+    if constexpr (D == NACT - 1) {
+        // deepest position with an all-zero prefix: the first q leaves of the walk touch every symbol
+        // exactly once, so they initialise E (no -DBL_MAX fill, LDPC_Decoder.cpp:277-280, needed).
+        constexpr int CH = (Q % 8 == 0) ? 8 : 1;
+        for (int k0 = 0; k0 < Q; k0 += CH) {
+            float v[CH];
+            int m[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const float2 pr = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (k0 + i));
+                v[i] = pr.x;
+                m[i] = __float_as_int(pr.y);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                c.s = c.s + v[i];
+                c.E[(symbase ^ m[i]) * c.TC] = c.s;
+                c.s = c.s - v[i];
+            }
+        }
+    } else {
+        c.s = c.s + c.v0[D];
+        nb_t0<D + 1, NACT, Q>(c, symbase ^ c.m0[D]);
+        c.s = c.s - c.v0[D];
+        constexpr int CH = ((Q - 1) % 7 == 0) ? 7 : 1;
+        for (int k0 = 1; k0 < Q; k0 += CH) {
+            float v[CH], sl[CH], ev[CH];
+            int m[CH], sy[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const float2 pr = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (k0 + i));
+                v[i] = pr.x;
+                m[i] = __float_as_int(pr.y);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                c.s = c.s + v[i];
+                nb_t1<D + 1, NACT>(c, symbase ^ m[i], sl[i], sy[i]);
+                c.s = c.s - v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) ev[i] = c.E[sy[i] * c.TC];
+#pragma unroll
+            for (int i = 0; i < CH; i++)
+                if (sl[i] > ev[i]) c.E[sy[i] * c.TC] = sl[i]; // :322-325
+        }
+    }
+}
+
+// General conf(Nm, Nc) walk (LDPC_Decoder.cpp:319-359), the reference's recursion as is.
+template <int D, int NACT> __device__ void nb_conf(NbCn<NACT> &c, int symbase, int diff, int Nm, int Nc)
+{
+    if constexpr (D == NACT) {
+        float *e = c.E + symbase * c.TC;
+        if (c.s > *e) *e = c.s;
+    } else {
+        for (int k = 0; k < Nm; k++) {
+            float v;
+            int m;
+            if (k == 0) { v = c.v0[D]; m = c.m0[D]; }
+            else if (k == 1) { v = c.v1[D]; m = c.m1[D]; }
+            else {
+                const float2 pr = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * k);
+                v = pr.x;
+                m = __float_as_int(pr.y);
+            }
+            c.s = c.s + v;
+            const int d2 = diff + (k != 0 ? 1 : 0);
+            const bool go = d2 <= Nc;
+            if (go) nb_conf<D + 1, NACT>(c, symbase ^ m, d2, Nm, Nc);
+            c.s = c.s - v;
+            if (!go) break;
+        }
+    }
+}
+
+template <int W, int Q>
+__device__ void nb_cn_update(const NbArgs &a, const float *pairs, float *E, int TC, int row, int e, int thr)
+{
+    constexpr int NACT = W - 1;
+    NbCn<NACT> c;
+    c.E = E + thr;
+    c.pairs = pairs;
+    c.TC = TC;
+    const int PST = nb_pair_stride(a.q);
+#pragma unroll
+    for (int i = 0; i < NACT; i++) {
+        const int pos = i + (i >= e ? 1 : 0); // ascending positions, skipping `except` (:327-331)
+        c.pb[i] = a.cn_src[row * a.dc + pos] * PST;
+        const float2 p0 = *reinterpret_cast<const float2 *>(pairs + c.pb[i]);
+        const float2 p1 = *reinterpret_cast<const float2 *>(pairs + c.pb[i] + 2);
+        c.v0[i] = p0.x; c.m0[i] = __float_as_int(p0.y);
+        c.v1[i] = p1.x; c.m1[i] = __float_as_int(p1.y);
+    }
+    c.s = 0.0f;
+    nb_t0<0, NACT, Q>(c, 0); // ConstructConf(GFQ, 1) :286
+    c.s = 0.0f;
+    int Nc = a.Nc;
+    if (a.Nc == a.dcmax_cfg - 1) Nc = W - 1; // :294-297
+    nb_conf<0, NACT>(c, 0, 0, a.Nm, Nc);     // ConstructConf(EMS_Nm, EMS_Nc) :300
+}
+
+template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = kNbThreads / 64;
+    const int N = a.N, M = a.M, q = a.q, dv = a.dv, dc = a.dc;
+    const int NE = N * dv, TC = M * dc, PST = nb_pair_stride(q);
+    float *pairs = lds;                    // [NE][PST]
+    float *E = pairs + NE * PST;           // [q][TC]
+    int *outs = reinterpret_cast<int *>(E + q * TC);  // [N]
+    int *flag = outs + N;                  // [4]
+    unsigned char *mulb = reinterpret_cast<unsigned char *>(flag + 4); // [q][q]
+
+    for (int i = tid; i < q * q; i += kNbThreads) mulb[i] = a.mul[i];
+    for (int i = tid; i < q * TC; i += kNbThreads) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+
+    const float *Lch = a.Lch + (size_t)frame * N * (q - 1);
+    float *LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
+    const bool active = lane < q - 1;          // lanes 0..q-2 <-> field elements 1..q-1
+    const int sym = active ? lane + 1 : 0;     // lane q-1 carries element 0 (value 0, :250)
+    int it = 0, ok = 0;
+    while (it < a.max_iter) {
+        it++;
+        // ---- A: variable nodes ------------------------------------------------------------
+        for (int col = wave; col < N; col += nwaves) {
+            const int w = a.vn_w[col];
+            float llr = active ? Lch[col * (q - 1) + lane] : 0.0f;
+            float c2[kNbMaxDv];
+#pragma unroll
+            for (int d = 0; d < kNbMaxDv; d++) {
+                c2[d] = 0.0f;
+                if (d < w) {
+                    const int thr = a.vn_thr[col * dv + d], h = a.vn_gf[col * dv + d];
+                    const float e0 = E[thr];
+                    const float ev = E[mulb[sym * q + h] * TC + thr];
+                    c2[d] = (float)((double)(ev - e0) / 1.2); // :309, double division
+                    llr = llr + c2[d];                         // :208-213, ascending d
+                }
+            }
+            // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
+            const float v = active ? llr : -__builtin_inff();
+            const float mx = nb_wave_max(v);
+            const unsigned long long eq = __ballot(active && v == mx);
+            const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
+            if (lane == 0) outs[col] = dec;
+            if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
+#pragma unroll
+            for (int d = 0; d < kNbMaxDv; d++)
+                if (d < w && lane < q) pairs[(col * dv + d) * PST + 2 * lane] = active ? llr - c2[d] : 0.0f; // :241-251
+        }
+        __syncthreads();
+        // ---- S: syndrome (:218-238) ----------------------------------------------------------
+        if (tid < M) {
+            int s = 0;
+            for (int i = 0; i < a.cn_w[tid]; i++) s ^= mulb[outs[a.cn_vn[tid * dc + i]] * q + a.cn_gf[tid * dc + i]];
+            if (s) flag[0] = 1;
+        }
+        __syncthreads();
+        if (flag[0] == 0) {
+            it--; // :236
+            ok = 1;
+            break;
+        }
+        // ---- B: stable descending sort of every v2c vector (:17-36, :253-269) -----------------
+        for (int edge = wave; edge < NE; edge += nwaves) {
+            const int col = edge / dv, d = edge - col * dv;
+            if (d >= a.vn_w[col]) continue;
+            const int h = a.vn_gf[edge];
+            const float val = (lane < q) ? pairs[edge * PST + 2 * lane] : 0.0f;
+            // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
+            const uint32_t b = __float_as_uint(val + 0.0f);
+            const uint32_t ua = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
+            const unsigned long long keyk = ((unsigned long long)ua << 32) | (unsigned)(63 - lane);
+            int rank = 0; // # elements that precede this one = # greater + # equal with a smaller index
+#pragma unroll
+            for (int j = 0; j < Q; j++) {
+                const uint32_t hj = __builtin_amdgcn_readlane(ua, j);
+                const unsigned long long keyj = ((unsigned long long)hj << 32) | (unsigned)(63 - j);
+                rank += (keyj > keyk) ? 1 : 0;
+            }
+            if (lane < q) {
+                float2 pr;
+                pr.x = val;
+                pr.y = __int_as_float((int)mulb[sym * q + h]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
+                *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * rank) = pr;
+            }
+        }
+        __syncthreads();
+        // ---- C: check nodes (:272-303) -----------------------------------------------------------
+        if (tid < TC) {
+            const int row = tid / dc, e = tid - row * dc, w = a.cn_w[row];
+            if (e < w) {
+                switch (w) {
+                case 2: nb_cn_update<2, Q>(a, pairs, E, TC, row, e, tid); break;
+                case 3: nb_cn_update<3, Q>(a, pairs, E, TC, row, e, tid); break;
+                case 4: nb_cn_update<4, Q>(a, pairs, E, TC, row, e, tid); break;
+                case 5: nb_cn_update<5, Q>(a, pairs, E, TC, row, e, tid); break;
+                case 6: nb_cn_update<6, Q>(a, pairs, E, TC, row, e, tid); break;
+                default: break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) flag[0] = 0; // next write is two barriers away, last read was two barriers ago
+    }
+    // ---- outputs ------------------------------------------------------------------------------
+    for (int i = tid; i < N; i += kNbThreads) a.out[(size_t)frame * N + i] = outs[i];
+    if (tid == 0) {
+        a.iters[frame] = it;
+        a.ok[frame] = ok;
+    }
+    if (a.c2v && tid < TC) {
+        const int row = tid / dc, e = tid - row * dc;
+        float *o = a.c2v + ((size_t)frame * TC + tid) * (q - 1);
+        if (e < a.cn_w[row]) {
+            const int h = a.cn_gf[tid];
+            const float e0 = E[tid];
+            for (int k = 1; k < q; k++) o[k - 1] = (float)((double)(E[mulb[k * q + h] * TC + tid] - e0) / 1.2);
+        } else {
+            for (int k = 1; k < q; k++) o[k - 1] = 0.0f;
+        }
+    }
+}
+
+// Demodulate, BPSK branch (LDPC_Decoder.cpp:139-157): one thread per (frame, symbol, element).
+__global__ __launch_bounds__(256) void k_nb_demod_bpsk(const float *rx, float sigma, int B, int N, int q, int m, float *Lch)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * N * (q - 1);
+    if (id >= total) return;
+    const int k = (int)(id % (q - 1)) + 1;
+    const size_t bs = id / (q - 1); // b*N + s
+    const float *r = rx + bs * m;
+    const float s2 = sigma * sigma;
+    float acc = 0.0f;
+    for (int b = 0; b < m; b++)
+        if ((k & (1 << b)) != 0) acc += (float)(-2) * r[b] / s2;
+    Lch[id] = acc;
+}
+
+// Statistic (Simulation.cpp:256-279): one thread per frame.
+__global__ __launch_bounds__(256) void k_nb_statistic(const int *out, const int *iters, const int *ok, const int *cw, int B, int N,
+                                                      long long *counters)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    long long v[4] = {0, 0, 0, 0};
+    if (f < B) {
+        int err = 0;
+        for (int i = 0; i < N; i++) err += (out[(size_t)f * N + i] != cw[i]) ? 1 : 0;
+        v[0] = err != 0;
+        v[1] = err;
+        v[2] = iters[f];
+        v[3] = ok[f];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        long long x = v[c];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long *)&counters[c], (unsigned long long)x);
+    }
+}
+
+} // namespace cldpc

@@ -1,0 +1,94 @@
+/*
+ * nbldpc.h -- C ABI of the MI355X-native GF(q) non-binary LDPC EMS decoder.
+ *
+ * Drop-in boundary for the reference's NB hot path (gsw4869/CUDA_LDPC, directory
+ * myNBLDPC/): Decoding_EMS (include/LDPC_Decoder.h:13, src/LDPC_Decoder.cpp:172-317)
+ * and its GPU twin Decoding_EMS_GPU (include/Decode_GPU.cuh:17).  Canonical
+ * semantics = the reference's CPU decoder (the only path of the reference whose float
+ * operation order is defined); results are bit-identical to it.
+ *
+ * The reference decodes ONE frame per call out of pointer-rich VN/CN objects; here a
+ * call decodes a batch of B independent frames from flat arrays:
+ *   L_ch          float [B][N][q-1]   element k-1 <-> field element k (element 0 has LLR 0),
+ *                                     what Demodulate leaves in VN[i].L_ch (LDPC_Decoder.cpp:139-157)
+ *   DecodeOutput  int32 [B][N]        hard symbols (Decoding_EMS argument of the same name)
+ *   iter_number   int32 [B]           as the reference leaves it: decremented once on success
+ *                                     (LDPC_Decoder.cpp:232-238), == maxIT on failure
+ *   ok            int32 [B]           the reference's return value (1 = zero syndrome reached)
+ * Graph arrays flatten VN[]/CN[] (include/struct.h:27-45), -1 padded:
+ *   vn_weight[N], vn_linkCNs[N][dvmax], vn_linkCNs_GF[N][dvmax]
+ *   cn_weight[M], cn_linkVNs[M][dcmax], cn_linkVNs_GF[M][dcmax]
+ * All functions return NBLDPC_OK or a negative code; nbldpc_last_error() has the text.
+ */
+#ifndef CUDA_LDPC_AMD_NBLDPC_H
+#define CUDA_LDPC_AMD_NBLDPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBLDPC_OK 0
+#define NBLDPC_EINVAL (-1)
+#define NBLDPC_ENOMEM (-2)
+#define NBLDPC_EHIP (-3)
+#define NBLDPC_EIO (-4)
+#define NBLDPC_EUNSUPPORTED (-5)
+
+typedef struct nbldpc_code nbldpc_code;
+
+/* Replaces Get_H (src/Simulation.cpp:347-467): "N M q / dvmax dcmax / N column weights / M row weights /
+ * per VN (cn_1based, gf)*w / per CN (vn_1based, gf)*w".  Call with all arrays NULL to obtain
+ * dims[0..4] = N, M, q, dvmax, dcmax, then again with arrays sized from them (host memory). */
+int nbldpc_read_matrix(const char *path, int dims[5], int *vn_weight, int *vn_linkCNs, int *vn_linkCNs_GF, int *cn_weight,
+                       int *cn_linkVNs, int *cn_linkVNs_GF);
+
+/* Replaces GFInitial (src/GF.cpp:68-117): reads "Multiply Table" q*q, "Add Table" q*q, "Inverse Table" q. */
+int nbldpc_gf_load(const char *path, int q, unsigned *TableMultiply, unsigned *TableAdd, unsigned *TableInverse);
+
+/* The same tables computed from the primitive polynomial (e.g. 67 = x^6+x+1 for GF(64), first line of
+ * GF/Arith.Table.GF.64.txt); polynomial-basis representation, add == XOR. */
+int nbldpc_gf_generate(int q, unsigned primitive_poly, unsigned *TableMultiply, unsigned *TableAdd, unsigned *TableInverse);
+
+/* Upload a code.  TableMultiply: host unsigned [q][q].  Supported by the fused kernel of this round:
+ * q a power of two <= 64, row weights 2..6, message state within one CU's LDS. */
+int nbldpc_code_create(int N, int M, int q, int dvmax, int dcmax, const int *vn_weight, const int *vn_linkCNs,
+                       const int *vn_linkCNs_GF, const int *cn_weight, const int *cn_linkVNs, const int *cn_linkVNs_GF,
+                       const unsigned *TableMultiply, nbldpc_code **code);
+int nbldpc_code_destroy(nbldpc_code *code);
+
+/* Replaces Decoding_EMS / Decoding_EMS_GPU for a batch (all pointers DEVICE memory).
+ *   EMS_Nm, EMS_Nc   reference macros EMS_NM / EMS_NC (define.h:31-32)
+ *   maxIT            reference macro maxIT (define.h:35)
+ *   maxdc_cfg        reference macro maxdc (define.h:28), used by the `EMS_Nc == maxdc - 1` test
+ *                    (LDPC_Decoder.cpp:294); pass 0 for the code's dcmax
+ *   LLR     optional float [B][N][q-1]       VN[].LLR of the last executed iteration
+ *   L_c2v   optional float [B][M][dcmax][q-1] CN[].L_c2v as the reference leaves it
+ *   stream  hipStream_t; the call is asynchronous. */
+int nbldpc_ems_decode_batch(nbldpc_code *code, const float *L_ch, int B, int EMS_Nm, int EMS_Nc, int maxIT, int maxdc_cfg,
+                            int *DecodeOutput, int *iter_number, int *ok, float *LLR, float *L_c2v, void *stream);
+
+/* Replaces Demodulate, BPSK branch (src/LDPC_Decoder.cpp:132-157), on the device:
+ * rx float [B][N*m] (m = log2 q, bit b of symbol s at s*m+b) -> L_ch float [B][N][q-1]. */
+int nbldpc_demodulate_bpsk(const nbldpc_code *code, const float *rx, float sigma, int B, float *L_ch, void *stream);
+
+/* Device-side Statistic (src/Simulation.cpp:256-279) over a decoded batch: counters device int64[4],
+ * ACCUMULATED: [0] num_Error_Frames [1] num_Error_Bits (symbol errors, sic) [2] Total_Iteration [3] frames ok.
+ * CodeWord_sym: device int32 [N]. */
+int nbldpc_statistic(const nbldpc_code *code, const int *DecodeOutput, const int *iter_number, const int *ok,
+                     const int *CodeWord_sym, int B, long long *counters, void *stream);
+
+/* Host input generator, bit-identical to the reference (BPSK, n_QAM 2): Modulate of the codeword bits
+ * (src/main.cu:203-211, Constellation/BPSK.txt: bit 0 -> +1, bit 1 -> -1) + AWGNChannel_CPU
+ * (src/LDPC_Encoder.cpp:41-68: four RandomModule draws per bit, cos branch).  rx: HOST float [N*m] for
+ * ONE frame; seed[3] advanced in place. */
+int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *CodeWord_sym, int N, int m, float *rx);
+
+/* sigma of a sweep point (src/main.cu:221-228). */
+float nbldpc_sigma(float SNR, int snrtype, int n_QAM, float rate);
+
+const char *nbldpc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

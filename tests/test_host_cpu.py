@@ -1,0 +1,141 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol; host logic (graph builders,
+readers, GF tables, channel generators) equals the oracle's restatement of the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, ROOT
+
+BL = os.path.join(DATA, "bldpc")
+NB = os.path.join(DATA, "nb")
+
+
+@pytest.fixture(scope="module")
+def C():
+    import cuda_ldpc_amd
+    return cuda_ldpc_amd
+
+
+@pytest.fixture(scope="module")
+def nbm(C):
+    from cuda_ldpc_amd import nbldpc
+    return nbldpc
+
+
+def test_abi_exports_every_declared_symbol(C):
+    from cuda_ldpc_amd._lib import SO_PATH
+    so = ctypes.CDLL(SO_PATH)
+    declared = []
+    for h in ("bldpc.h", "nbldpc.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared += re.findall(r"\b((?:nb)?bldpc_\w+)\s*\(", text) + re.findall(r"\b(nbldpc_\w+)\s*\(", text)
+    declared = sorted(set(declared))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(so, name), "missing export %s" % name
+
+
+def test_no_oracle_on_product_path():
+    """The product package must not import / link / dlopen the oracle."""
+    pkg = os.path.join(ROOT, "cuda_ldpc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read().lower()
+                assert "oracle" not in src and "pyoracle" not in src and "orc_" not in src, f
+    so = open(os.path.join(pkg, "libcuda_ldpc_amd.so"), "rb").read()
+    assert b"liboracle" not in so and b"orc_bldpc" not in so and b"orc_nb" not in so
+
+
+ALL_MATRICES = sorted(f for f in os.listdir(BL) if f.endswith(".txt"))
+
+
+@pytest.mark.parametrize("fn", ALL_MATRICES)
+def test_get_h_transform_h_all_matrices(C, orc, fn):
+    m = re.match(r"J(\d+)_L(\d+)_Z(\d+)", fn)
+    J, L, Z = (int(x) for x in m.groups()) if m else (12, 69, 256)
+    H, wc, wv = C.Get_H(os.path.join(BL, fn), J, L)
+    for lit in (False, True):
+        oc = orc.BinaryCode(os.path.join(BL, fn), J, L, Z, literal=lit)
+        assert np.array_equal(H, oc.H) and np.array_equal(wc, oc.wc) and np.array_equal(wv, oc.wv)
+        assert np.array_equal(C.Transform_H(H, J, L, Z, wc, wv, as_written=lit), oc.addr)
+    # the corrected table is a bijection between edges and Memory_RQ slots; the as-written one is not
+    addr = C.Transform_H(H, J, L, Z, wc, wv).reshape(L * Z, -1)
+    used = np.concatenate([addr[l * Z:(l + 1) * Z, :wv[l]].reshape(-1) for l in range(L)])
+    assert len(np.unique(used)) == used.size == int((H != -1).sum()) * Z
+    lit = C.Transform_H(H, J, L, Z, wc, wv, as_written=True).reshape(L * Z, -1)
+    usedl = np.concatenate([lit[l * Z:(l + 1) * Z, :wv[l]].reshape(-1) for l in range(L)])
+    if fn == "J4_L24_Z96_BlockH.txt":
+        assert usedl.size - len(np.unique(usedl)) == 1542  # collisions counted in SURVEY F3
+
+
+def test_binary_channel_equals_oracle(C, orc):
+    for snr in (0.0, 3.0, 12.999992):
+        s1 = np.array([173, 173, 173], np.int32)
+        s2 = s1.copy()
+        a = C.AWGNChannel_CPU(s1, C.sigma_of(snr), 2304, 5)
+        b = orc.bldpc_awgn(s2, orc.bldpc_sigma(snr), 2304, 5)
+        assert np.array_equal(a.reshape(-1).view(np.uint32), b.view(np.uint32)) and np.array_equal(s1, s2)
+    assert C.sigma_of(2.0, snrtype=0, rate=0.5) == orc.bldpc_sigma(2.0, 0, 0.5)
+    cw = np.random.default_rng(0).integers(0, 2, (100, 3)).astype(np.int32)
+    s1 = np.array([1, 2, 3], np.int32); s2 = s1.copy()
+    assert np.array_equal(C.AWGNChannel_CPU(s1, 0.7, 100, 3, CodeWord=cw).reshape(-1), orc.bldpc_awgn(s2, 0.7, 100, 3, codeword=cw))
+
+
+def test_host_errors(C):
+    with pytest.raises(Exception):
+        C.Get_H(os.path.join(BL, "J4_L24_Z96_BlockH.txt"), 40, 24)   # file too short
+    with pytest.raises(Exception):
+        C.Transform_H(np.full(96, 200, np.int32), 4, 24, 96, np.zeros(5, np.int32) + 20, np.zeros(25, np.int32) + 4)
+
+
+def test_gf_tables(nbm, orc):
+    oc = orc.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    mul, add, inv = nbm.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    assert np.array_equal(mul.reshape(-1), oc.mul) and np.array_equal(add.reshape(-1), oc.add) and np.array_equal(inv, oc.inv)
+    gmul, gadd, ginv = nbm.GFInitial(64, primitive_poly=67)  # title line of the reference's table file
+    assert np.array_equal(gmul, mul) and np.array_equal(gadd, add) and np.array_equal(ginv, inv)
+    with pytest.raises(Exception):
+        nbm.GFInitial(64, primitive_poly=64 + 1)  # x^6+1 is reducible
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/myNBLDPC/GF"), reason="reference tree absent (GPU box)")
+@pytest.mark.parametrize("q,poly", [(4, 7), (8, 11), (16, 19), (32, 37), (64, 67), (128, 137), (256, 285)])
+def test_gf_generator_matches_every_reference_table(nbm, q, poly):
+    path = "/root/reference/myNBLDPC/GF/Arith.Table.GF.%d.txt" % q
+    title = open(path).readline()
+    assert str(poly) in title, title
+    mul, add, inv = nbm.GFInitial(q, path)
+    gmul, gadd, ginv = nbm.GFInitial(q, primitive_poly=poly)
+    assert np.array_equal(gmul, mul) and np.array_equal(gadd, add) and np.array_equal(ginv, inv)
+
+
+def test_nb_channel_equals_oracle_and_reference(nbm, orc):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nb_ref_3dB.npz"))
+    oc = orc.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+
+    class Shape:  # host-only stand-in for NBCode (creating a device code needs a GPU)
+        N, m = 96, 6
+    assert np.float32(nbm.sigma_of(3.0, oc.rate)) == np.float32(g["sigma"])
+    seed = np.array([173, 173, 173], np.int32)
+    for fr in range(4):
+        rx = nbm.AWGNChannel_CPU(seed, float(g["sigma"]), Shape, g["cw"])
+        assert np.array_equal(rx.view(np.uint32), g["rx"][fr].view(np.uint32))  # the reference's own samples
+
+
+def test_nb_matrix_reader(nbm, orc):
+    from cuda_ldpc_amd._lib import lib
+    oc = orc.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    dims = np.zeros(5, np.int32)
+    p = os.path.join(NB, "BDS.576.288.GF.64.txt").encode()
+    assert lib.nbldpc_read_matrix(p, dims.ctypes.data_as(ctypes.c_void_p), None, None, None, None, None, None) == 0
+    assert list(dims) == [96, 48, 64, 2, 4]
+    arrs = [np.zeros(n, np.int32) for n in (96, 192, 192, 48, 192, 192)]
+    assert lib.nbldpc_read_matrix(p, dims.ctypes.data_as(ctypes.c_void_p), *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs]) == 0
+    for a, b in zip(arrs, (oc.vn_w, oc.vn_cn, oc.vn_gf, oc.cn_w, oc.cn_vn, oc.cn_gf)):
+        assert np.array_equal(a, b)
+    assert lib.nbldpc_read_matrix(b"/nonexistent", dims.ctypes.data_as(ctypes.c_void_p), None, None, None, None, None, None) != 0

@@ -1,0 +1,157 @@
+"""GPU parity tests of the GF(q) EMS decoder (through the C ABI, include/nbldpc.h).
+
+Bit-exact (symbols, iteration counts, return flags, and the float LLR / c2v state compared as uint32)
+against (1) dumps of the REFERENCE's own CPU decoder committed under tests/golden/nb_ref_*.npz and
+(2) the CPU oracle on further seeded inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DATA, GOLDEN
+
+pytestmark = pytest.mark.gpu
+NB = os.path.join(DATA, "nb")
+
+
+@pytest.fixture(scope="module")
+def nb():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cuda_ldpc_amd import nbldpc
+    return nbldpc
+
+
+@pytest.fixture(scope="module")
+def code(nb):
+    mul, _, _ = nb.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    return nb.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), mul)
+
+
+@pytest.fixture(scope="module")
+def ocode(orc):
+    return orc.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+
+
+@pytest.mark.parametrize("snr", [2, 3, 5])
+def test_matches_reference_dump(nb, code, orc, snr):
+    """Inputs = the reference's channel samples; outputs vs the reference's own Decoding_EMS."""
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    rx = torch.from_numpy(g["rx"]).cuda()
+    Lch = nb.Demodulate(code, rx, sigma)
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    Lch_h = Lch.cpu().numpy()
+    out, it, ok = r["DecodeOutput"].cpu().numpy(), r["iter_number"].cpu().numpy(), r["ok"].cpu().numpy()
+    LLR, c2v = r["LLR"].cpu().numpy(), r["L_c2v"].cpu().numpy()
+    assert np.array_equal(it, g["it"]) and np.array_equal(ok, g["ok"])
+    assert np.array_equal(out, g["out"])
+    for fr in range(rx.shape[0]):
+        assert orc.fold_hash(Lch_h[fr]) == int(g["Lch_hash"][fr]), "L_ch frame %d" % fr
+        assert orc.fold_hash(LLR[fr]) == int(g["LLR_hash"][fr]), "LLR frame %d" % fr
+        assert orc.fold_hash(c2v[fr]) == int(g["c2v_hash"][fr]), "c2v frame %d" % fr
+    for i, fr in enumerate(g["full_frames"]):
+        assert np.array_equal(LLR[fr].view(np.uint32), g["full_LLR"][i].view(np.uint32))
+        assert np.array_equal(c2v[fr].view(np.uint32), g["full_c2v"][i].view(np.uint32))
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 6])
+def test_per_iteration_state_vs_oracle(nb, code, ocode, orc, iters):
+    """Per-iteration LLR snapshots: run with maxIT = k and compare the whole float state bitwise."""
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(2.5, code.rate)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, cw) for _ in range(6)])
+    Lch = nb.Demodulate(code, torch.from_numpy(rx).cuda(), sigma)
+    r = nb.Decoding_EMS(code, Lch, 2, 2, iters, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(rx.shape[0]):
+        want = orc.nb_ems_decode(ocode, orc.nb_demodulate(ocode, rx[b], sigma), 2, 2, iters, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
+@pytest.mark.parametrize("Nm,Nc", [(2, 2), (3, 2), (2, 3), (4, 1), (1, 1)])
+def test_other_ems_parameters(nb, code, ocode, orc, Nm, Nc):
+    """EMS_NM / EMS_NC other than the default, including EMS_NC == maxdc-1 (-> Nc = w-1, LDPC_Decoder.cpp:294)."""
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    seed = np.array([11, 22, 33], np.int32)
+    sigma = nb.sigma_of(3.0, code.rate)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, cw) for _ in range(3)])
+    Lch = nb.Demodulate(code, torch.from_numpy(rx).cuda(), sigma)
+    r = nb.Decoding_EMS(code, Lch, Nm, Nc, 8, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(rx.shape[0]):
+        want = orc.nb_ems_decode(ocode, orc.nb_demodulate(ocode, rx[b], sigma), Nm, Nc, 8, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
+def test_ties_zeros_and_extremes(nb, code, ocode, orc):
+    """Inputs full of exact ties, zeros and +-0: the stable sort order and first-max decision must still match."""
+    rng = np.random.default_rng(3)
+    B = 4
+    Lch = rng.integers(-3, 4, size=(B, code.N, code.q - 1)).astype(np.float32)   # heavy ties
+    Lch[0, :, ::5] = -0.0
+    Lch[1] *= 1e30
+    Lch[2] *= 1e-40  # denormals
+    r = nb.Decoding_EMS(code, torch.from_numpy(Lch).cuda(), 2, 2, 5, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        want = orc.nb_ems_decode(ocode, Lch[b], 2, 2, 5, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
+def test_full_size_batch_properties(nb, code, ocode, orc):
+    """BASELINE config 5 size (16384 frames): a 32-frame oracle-checked block tiled 512 times; every tile must
+    decode identically (frames are independent) and transmitted codewords that decode must be codewords."""
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(3.0, code.rate)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, cw) for _ in range(32)])
+    rxt = torch.from_numpy(rx).cuda().repeat(512, 1).contiguous()
+    Lch = nb.Demodulate(code, rxt, sigma)
+    r = nb.Decoding_EMS(code, Lch, 2, 2, 20)
+    torch.cuda.synchronize()
+    out = r["DecodeOutput"].view(512, 32, code.N)
+    assert bool((out == out[:1]).all())
+    it = r["iter_number"].view(512, 32)
+    assert bool((it == it[:1]).all())
+    want = orc.nb_ems_decode_batch(ocode, np.stack([orc.nb_demodulate(ocode, rx[b], sigma) for b in range(32)]), 2, 2, 20)
+    assert np.array_equal(out[0].cpu().numpy(), want["out"])
+    assert np.array_equal(it[0].cpu().numpy(), want["it"])
+    okm = r["ok"].view(512, 32)[0].cpu().numpy().astype(bool)
+    assert np.array_equal(okm.astype(np.int32), want["ok"])
+    # zero syndrome on success
+    mul = ocode.mul.reshape(64, 64)
+    o = out[0].cpu().numpy()
+    for b in np.nonzero(okm)[0]:
+        for row in range(code.M):
+            s = 0
+            for i in range(code.cn_weight[row]):
+                s ^= int(mul[o[b, code.cn_linkVNs[row, i]], code.cn_linkVNs_GF[row, i]])
+            assert s == 0
+    # statistics kernel
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    nb.Statistic(code, counters, r, torch.from_numpy(cw).cuda())
+    c = counters.cpu().tolist()
+    errs = (o != cw[None, :]).sum(axis=1)
+    assert c[0] == 512 * int((errs != 0).sum()) and c[1] == 512 * int(errs.sum()) and c[2] == 512 * int(want["it"].sum())
+
+
+def test_argument_errors(nb, code):
+    with pytest.raises(Exception):
+        nb.Decoding_EMS(code, torch.zeros((2, code.N, 10), device="cuda"))
+    with pytest.raises(Exception):
+        nb.Decoding_EMS(code, torch.zeros((2, code.N, 63), device="cuda"), maxIT=0)
+    with pytest.raises(Exception):
+        nb.GFInitial(64, "/nonexistent")
