@@ -37,6 +37,8 @@ WORKLOADS = {
     "J4_L24_Z96": ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 65536, 3.0, 50),
     "J32_L64_Z64": ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 32768, 0.0, 50),
     "J15_L30_Z1280": ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, 1024, 0.0, 50),
+    # GF(64) EMS (BASELINE.json configs[4]): frames per GPU, Eb/N0 dB, maxIT (reference default 20, define.h:35)
+    "NB_BDS_GF64": ("BDS.576.288.GF.64.txt", 0, 0, 0, 16384, 3.0, 20),
 }
 
 
@@ -57,20 +59,112 @@ def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
     """Oracle (CPU port of the reference kernels, OpenMP over frames) on a bounded sample. Checker code,
     used here ONLY as the reported CPU baseline -- never on the product path."""
     from oracle import pyoracle as orc
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = cpu_threads()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     code = orc.BinaryCode(os.path.join(ROOT, "data", "bldpc", name), J, L, Z)
     if nframes <= 0:
-        nframes = 128 * cores  # ~115 cw/s/core at 50 iterations -> on the order of 10-20 s of CPU work
-    nframes = min(nframes, y_block.shape[1])
-    y = np.ascontiguousarray(y_block[:, :nframes]).reshape(-1)
+        nframes = 1536 * cores // 16 * 16  # ~115 cw/s/core at 50 iterations -> on the order of 10-20 s of CPU work
+    reps = (nframes + y_block.shape[1] - 1) // y_block.shape[1]
+    y = np.ascontiguousarray(np.tile(y_block, (1, reps))[:, :nframes]).reshape(-1)
     orc.bldpc_decode(code, y, nframes, 1, early_exit=0)  # touch pages / spin up the OpenMP threads
     t0 = time.perf_counter()
     orc.bldpc_decode(code, y, nframes, iters, early_exit=0)
     dt = time.perf_counter() - t0
     return {"value": nframes / dt, "unit": "codewords/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same 4096-frame block, %d iterations, oracle/bldpc_oracle.c with OpenMP over frames, %.1f s"
+            "sample": "%d frames of the same tiled 4096-frame block, %d iterations, oracle/bldpc_oracle.c (port: the binary reference has no CPU path), OpenMP over frames, %.1f s"
                       % (nframes, iters, dt)}
+
+
+def cpu_threads():
+    """Host threads for the CPU baseline: this box's share for one GPU is 16 cores (gpurun contract)."""
+    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+
+
+def nb_cpu_baseline(snr, nframes):
+    """The REFERENCE's own CPU decoder (oracle/_ref/nb_ref, built from /root/reference/myNBLDPC/src/*.cpp;
+    single-threaded like the reference's THREAD_NUM 1) on the first frames of the same stream."""
+    import subprocess
+    from oracle import pyoracle as orc
+    ref = orc.ref_binary()
+    if ref is None:
+        return None
+    nframes = nframes or 300  # ~33 frames/s at 3 dB -> ~10 s
+    out = subprocess.check_output([ref, "time", str(snr), str(nframes)], cwd=os.path.join(ROOT, "data", "nb")).decode()
+    j = json.loads(out.strip().splitlines()[-1])
+    return {"value": j["frames_per_s"], "unit": "codewords/s", "cores": 1, "kind": "reference",
+            "sample": "first %d frames of the same seed-173 stream at Eb/N0 %.1f dB, reference Decoding_EMS (maxIT 20, early exit), "
+                      "mean %.2f iterations, %.1f s" % (nframes, snr, j["mean_iters"], j["seconds"])}
+
+
+def run_nb(args, rank, world, dev, dist):
+    from cuda_ldpc_amd import nbldpc as nb
+    name, _, _, _, frames, snr, iters = WORKLOADS[args.workload]
+    if args.frames:
+        frames = args.frames
+    nbd = os.path.join(ROOT, "data", "nb")
+    mul, _, _ = nb.GFInitial(64, os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
+    code = nb.NBCode(os.path.join(nbd, name), mul)
+    cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
+    block = min(1024, frames)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(snr, code.rate)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, cw) for _ in range(block)])
+    reps = (frames + block - 1) // block
+    rxt = torch.from_numpy(rx).to(dev).repeat(reps, 1)[:frames].contiguous()
+    Lch = nb.Demodulate(code, rxt, sigma)  # resident in HBM before the timed region
+    cwd = torch.from_numpy(cw).to(dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        nb.Statistic(code, counters, nb.Decoding_EMS(code, Lch, 2, 2, iters, stream=stream), cwd, stream=stream)
+    counters.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        r = nb.Decoding_EMS(code, Lch, 2, 2, iters, stream=stream)
+        ev[k][1].record(stream)
+        nb.Statistic(code, counters, r, cwd, stream=stream)
+    tot = counters.clone()
+    if world > 1:
+        dist.all_reduce(tot)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    if rank != 0:
+        return
+    n_all = frames * world * args.steps
+    alg_bytes = (4 * code.N * (code.q - 1) + 4 * code.N) * frames  # L_ch in + symbols out (SURVEY 8d)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    c = tot.cpu().tolist()
+    out = {
+        "metric": "decoded codewords/sec (GF(64) EMS, maxIT %d, per-frame syndrome exit as the reference)" % iters,
+        "value": n_all / elapsed, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "myNBLDPC BDS N576_K288 GF(64) EMS(Nm=2,Nc=2) batch=%d codewords/GPU Eb/N0=%.1fdB" % (frames, snr),
+                   "kernel": "nb_ems<q64> one frame per workgroup", "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        "stats": {"frames": n_all, "error_frames": c[0], "symbol_errors": c[1], "FER": c[0] / n_all, "SER": c[1] / n_all / code.N,
+                  "mean_iterations": c[2] / n_all},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb = nb_cpu_baseline(snr, args.cpu_frames)
+        if cb:
+            out["cpu_baseline"] = cb
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -82,14 +176,26 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0  # rehearsal of the N>1 code path on a one-GPU box (use with BENCH_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import cuda_ldpc_amd as C  # raises if the HIP extension is missing: no fallback
+
+    if args.workload.startswith("NB_"):
+        run_nb(args, rank, world, dev, dist if world > 1 else None)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     name, J, L, Z, frames, snr, iters = WORKLOADS[args.workload]
     if args.frames:

@@ -147,6 +147,7 @@ class SimCounters:
     Total_Iteration: int = 0
     num_False_Frames: int = 0
     num_Alarm_Frames: int = 0
+    SNR: float = 0.0
     _dev: object = field(default=None, repr=False)
 
     def ratios(self, length):

@@ -226,3 +226,32 @@ def test_argument_errors(C):
     bad = np.full(J * L, Z + 5, np.int32)
     with pytest.raises(Exception):
         C.BinaryCode.from_shifts(bad, J, L, Z)
+
+
+def test_simulation_gpu_loop_matches_oracle(C, orc):
+    """Simulation_GPU (Simulation.cu:12-171): batch loop + stop rule, counters vs a CPU replay of the same loop."""
+    from cuda_ldpc_amd.simulation import Simulation_GPU, format_row
+    J, L, Z, F = 4, 24, 96, 64
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    snr = 2.8
+    seed = np.array([173, 173, 173], np.int32)
+    SIM = C.SimCounters()
+    SIM.SNR = snr
+    rows = []
+    stop = Simulation_GPU(code, seed, C.sigma_of(snr), SIM, Num_Frames_OneTime=F, maxIT=50, leastErrorFrames=3, leastTestFrames=128,
+                          displayStep=F, log=rows.append)
+    assert stop == 1
+    # CPU replay
+    oseed = np.array([173, 173, 173], np.int32)
+    cnt = np.zeros(5, np.int64)
+    frames = 0
+    while True:
+        frames += F
+        y = orc.bldpc_awgn(oseed, orc.bldpc_sigma(snr), ocode.N, F)
+        r = orc.bldpc_decode(ocode, y, F, 50, early_exit=1)
+        if orc.bldpc_statistic(cnt, frames, r["D"], ocode.N, F, ocode.K, r["it"], least_err=3, least_frames=128):
+            break
+    assert frames == SIM.num_Frames and np.array_equal(seed, oseed)
+    assert [SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, SIM.num_False_Frames, SIM.num_Alarm_Frames] == cnt.tolist()
+    assert len(rows) == frames // F and rows[-1] == format_row(SIM, code.K)

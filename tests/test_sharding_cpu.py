@@ -1,0 +1,109 @@
+"""World-size-2 `gloo` tests of the multi-GPU path's host logic (CPU only).
+
+The N>1 data path is: cut the batch into contiguous frame ranges, each rank generates exactly its own
+slice of the reference's serial noise stream (LCG jump-ahead), decodes it, counts errors, and ONE
+all-reduce sums the five counters.  Here the decode of a shard is played by the CPU oracle (this is a
+test), the collective by gloo; the sharded result must equal the unsharded one.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import DATA, ROOT
+
+BL = os.path.join(DATA, "bldpc")
+
+
+def test_shard_frames_partition():
+    from cuda_ldpc_amd import sharding
+    for F in (1, 7, 8, 4096, 65536, 13):
+        for world in (1, 2, 3, 8):
+            got = [sharding.shard_frames(F, world, r) for r in range(world)]
+            assert sum(c for _, c in got) == F
+            nxt = 0
+            for first, c in got:
+                assert first == nxt
+                nxt += c
+    with pytest.raises(ValueError):
+        sharding.shard_frames(8, 2, 2)
+
+
+def test_lcg_jump_equals_serial_stream(orc):
+    from cuda_ldpc_amd import sharding
+    seed = np.array([173, 173, 173], np.int32)
+    s = seed.copy()
+    for k in (0, 1, 5, 4608, 100003):
+        s = seed.copy()
+        for _ in range(k):
+            orc.lib().orc_random_module(s.ctypes.data_as(__import__("ctypes").c_void_p))
+        assert np.array_equal(sharding.lcg_jump(seed, k), s), k
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, F, snr, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cuda_ldpc_amd as C
+    from cuda_ldpc_amd import sharding
+    from oracle import pyoracle as orc
+    J, L, Z = 4, 24, 96
+    path = os.path.join(BL, "J4_L24_Z96_BlockH.txt")
+    ocode = orc.BinaryCode(path, J, L, Z)
+    seed = np.array([173, 173, 173], np.int32)
+    first, count = sharding.shard_frames(F, world, rank)
+    my_seed = sharding.lcg_jump(seed, first * sharding.binary_draws_per_frame(ocode.N))
+    y = C.AWGNChannel_CPU(my_seed, C.sigma_of(snr), ocode.N, count)       # product host code, this rank's slice only
+    r = orc.bldpc_decode(ocode, y.reshape(-1), count, 50, early_exit=0)   # stand-in for the GPU decode of the shard
+    cnt = np.zeros(5, np.int64)
+    orc.bldpc_statistic(cnt, 0, r["D"], ocode.N, count, ocode.K, r["it"])
+    t = torch.from_numpy(cnt)
+    sharding.allreduce_counters(t, dist)                                   # the one collective of the path
+    q.put((rank, first, count, t.tolist(), y[:, :1].copy()))
+    dist.destroy_process_group()
+
+
+def test_world2_sharded_counters_equal_unsharded(orc):
+    F, snr, world = 12, 2.5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, snr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # unsharded reference run
+    ocode = orc.BinaryCode(os.path.join(BL, "J4_L24_Z96_BlockH.txt"), 4, 24, 96)
+    seed = np.array([173, 173, 173], np.int32)
+    y = orc.bldpc_awgn(seed, orc.bldpc_sigma(snr), ocode.N, F).reshape(ocode.N, F)
+    r = orc.bldpc_decode(ocode, y.reshape(-1), F, 50, early_exit=0)
+    cnt = np.zeros(5, np.int64)
+    orc.bldpc_statistic(cnt, 0, r["D"], ocode.N, F, ocode.K, r["it"])
+    for rank, first, count, tot, ycol in res:
+        assert tot == cnt.tolist()                                           # every rank holds the global sums
+        assert np.array_equal(ycol[:, 0].view(np.uint32), y[:, first].view(np.uint32))  # its slice of the serial stream
+    assert cnt[0] > 0  # the test point actually has frame errors to count
+
+
+def test_snr_grid_matches_reference_float_accumulation():
+    from cuda_ldpc_amd.simulation import snr_grid
+    g = snr_grid(0.0, 13.0, 0.2)
+    assert len(g) == 66 and g[0] == 0.0
+    assert np.float32(g[1]) == np.float32(0.200000003) and np.float32(g[3]) == np.float32(0.600000024)
+    assert abs(g[-1] - 12.9999924) < 1e-6
+    assert snr_grid(0, 5, 0.5) == [0.5 * i for i in range(11)]
