@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--workload", default="J4_L24_Z96", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "qc", "table"])
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU")
+    ap.add_argument("--iters", type=int, default=0, help="override the iteration count (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the cpu_baseline sample (0 = auto)")
     return ap.parse_args()
@@ -200,6 +201,8 @@ def main():
     name, J, L, Z, frames, snr, iters = WORKLOADS[args.workload]
     if args.frames:
         frames = args.frames
+    if args.iters:
+        iters = args.iters
     code = C.BinaryCode.from_blockh(os.path.join(ROOT, "data", "bldpc", name), J, L, Z)
     kernel = {"auto": C.KERNEL_AUTO, "qc": C.KERNEL_QC_LDS, "table": C.KERNEL_TABLE}[args.kernel]
     N = code.N

@@ -5,7 +5,7 @@ import os
 import torch  # noqa: F401  -- first, so that ONE HIP runtime (torch's) serves the whole process
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libcuda_ldpc_amd.so")
+SO_PATH = os.environ.get("CUDA_LDPC_AMD_SO") or os.path.join(_HERE, "libcuda_ldpc_amd.so")  # env: experiments only
 
 
 class ExtensionMissing(ImportError):

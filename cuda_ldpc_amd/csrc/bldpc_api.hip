@@ -25,7 +25,7 @@ struct bldpc_code {
     std::vector<int> level_begin; // node_list range of each VN level, size levels+1
     int *d_addr = nullptr, *d_node_list = nullptr;
     unsigned char *d_wv_blk = nullptr, *d_wc_blk = nullptr;
-    DevBuf rq, bad, cnt;
+    DevBuf rq, bad, cnt, bits, yg, errs;
     int *h_cnt = nullptr; // pinned
     QcPlan qc;            // fused LDS kernel description (frames_per_wg == 0: unavailable)
     const char *last_kernel = "none";
@@ -205,7 +205,7 @@ extern "C" int bldpc_code_destroy(bldpc_code *c)
     if (c->d_wv_blk) (void)hipFree(c->d_wv_blk);
     if (c->d_wc_blk) (void)hipFree(c->d_wc_blk);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-    c->rq.release(); c->bad.release(); c->cnt.release();
+    c->rq.release(); c->bad.release(); c->cnt.release(); c->bits.release(); c->yg.release(); c->errs.release();
     qc_plan_release(&c->qc);
     delete c;
     return BLDPC_OK;
@@ -286,8 +286,10 @@ extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, 
                         c->has_qc ? "message state exceeds LDS" : "built from an address table");
         CLDPC_HIP(c->bad.reserve((size_t)F * sizeof(unsigned long long)), BLDPC_ENOMEM);
         CLDPC_HIP(c->cnt.reserve(64), BLDPC_ENOMEM);
+        CLDPC_HIP(c->bits.reserve((size_t)F * (c->N / 32) * sizeof(unsigned)), BLDPC_ENOMEM);
+        CLDPC_HIP(c->yg.reserve(((size_t)F + 2) * c->N * sizeof(float)), BLDPC_ENOMEM);
         int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
-                          (unsigned long long *)c->cnt.p, c->h_cnt, itera, st);
+                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, st);
         c->last_kernel = c->qc.name;
         return r;
     }
@@ -304,13 +306,25 @@ extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, 
     return run_table<1>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
 }
 
-extern "C" int bldpc_statistic(const bldpc_code *c, const int *D, const int *cw, int F, int length, int itera, long long *counters,
+extern "C" int bldpc_statistic(const bldpc_code *cc, const int *D, const int *cw, int F, int length, int itera, long long *counters,
                                void *stream)
 {
+    bldpc_code *c = const_cast<bldpc_code *>(cc); // scratch only
     if (!c || !D || !counters || F <= 0) return fail(BLDPC_EINVAL, "bldpc_statistic: bad argument");
     if (length == 0) length = c->K;
     if (length < 0 || length > c->N) return fail(BLDPC_EINVAL, "bldpc_statistic: length=%d outside [0,%d]", length, c->N);
-    hipLaunchKernelGGL(k_statistic, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, D, cw, c->N, F, length, itera, counters);
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)F * sizeof(int) > c->errs.cap) {
+        CLDPC_HIP(c->errs.reserve((size_t)F * sizeof(int)), BLDPC_ENOMEM);
+        CLDPC_HIP(hipMemsetAsync(c->errs.p, 0, (size_t)F * sizeof(int), st), BLDPC_EHIP);
+    }
+    const int slices = std::max(1, std::min(64, length / 32));
+    const int rows = (length + slices - 1) / slices;
+    if (length > 0)
+        hipLaunchKernelGGL(k_stat_errors, dim3((unsigned)((F + 1023) / 1024), (unsigned)slices), dim3(256), 0, st, D, cw, F, length, rows,
+                           (int *)c->errs.p);
+    hipLaunchKernelGGL(k_stat_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, (int *)c->errs.p, D + (size_t)c->N * F, F, itera,
+                       counters);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
 }

@@ -1,213 +1,234 @@
 // bldpc_qc_kernel.hpp -- fused QC-LDPC flooding min-sum kernel (BLDPC_KERNEL_QC_LDS).
 //
 // One workgroup decodes NF*FP frames for ALL iterations without touching HBM in
-// between: channel values and the check-node outputs live in registers, the
-// messages in flight live in LDS.  Same arithmetic, in the same order, as the
-// reference's two kernels per iteration (bldpc_实习/LDPC_Decoder.cu:172-372),
-// none of their structure.
+// between: channel values live in registers, every message lives in LDS.  Same
+// arithmetic, in the same order, as the reference's two kernels per iteration
+// (bldpc_实习/LDPC_Decoder.cu:172-372), none of their structure.
 //
 // Mapping.  A block (j,l) with shift s connects check row r to variable column
 // (r+s) mod Z.  Lanes run along the circulant dimension: thread (g, p, t) owns
 //   * check rows   (j, t) for j = g, g+G, ...   of frame group p   (CN phase)
 //   * variables    (l, t) for l = g, g+G, ...   of frame group p   (VN phase)
 // and every lane carries NF (1 or 2) frames side by side, so LDS traffic is
-// ds_read_b64/ds_write_b64 and the VN sums are packed adds.  U = FP*Z is a
-// multiple of 64, hence g is wave-uniform and all table look-ups are scalar.
+// ds_read_b64/ds_write_b64 and the VN sums are packed adds.  A group of U lanes
+// (FP*Z rounded up to whole waves; surplus lanes idle) makes g wave-uniform, so
+// every table look-up is a scalar load.  The geometry (J, L, Z, FP, G, U) is a
+// template parameter: block and column offsets inside LDS become immediate
+// offsets of the ds_ instructions; only the shifts and the block positions are
+// run-time data (read once, in the prologue).
 //
 // Message exchange ("APP exchange", bit-identical to the reference's in-place
 // R/Q memory, SURVEY Appendix A note):
 //   VN phase: S = ((0+R_0)+R_1+...)+y in ascending block-row order (A.2); the
 //             thread reads R through the rotation (c-s) mod Z and publishes S
-//             aligned (one LDS write per VARIABLE instead of one per EDGE).
-//   CN phase: the check thread keeps its own last outputs R_p in registers,
-//             reads S of its neighbours through the rotation (r+s) mod Z, forms
-//             Q_p = S - R_p (the value the reference's VN kernel would have stored,
-//             LDPC_Decoder.cu:206-209), runs min-sum, publishes R aligned.
-// LDS per lane-slot: (E + N) * 4 * NF bytes per frame group instead of HBM
-// traffic of 16E + 8N bytes per frame and iteration.
+//             aligned: one LDS write per VARIABLE instead of one per EDGE.
+//   CN phase: the check thread reads S of its neighbours through the rotation
+//             (r+s) mod Z and its own previous outputs R_p (aligned), forms
+//             Q_p = S - R_p -- the value the reference's VN kernel would have
+//             stored (LDPC_Decoder.cu:206-209) -- runs min-sum, publishes R aligned.
+// LDS is read-cheap / write-expensive on gfx950 (ds_read_b64 256 B/clk,
+// ds_write_b64 ~85 B/clk per CU): this trades E writes for E extra reads.
+// Rotations are LDS addresses computed once and kept as 16-bit slot indices
+// packed two per VGPR.  The iteration loop is branch-free: rows lighter than WC
+// read a slot that always holds +inf (neutral for min1/min2/sign) and write into
+// the row's own padding blocks; columns lighter than WV read a slot that always
+// holds +0.0f (adding +0.0f to a sum that is never -0.0f is exact).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/bldpc.h"
 #include "bldpc_math.hpp"
 #include "common.hpp"
 
+#ifndef QC_ABLATE
+#define QC_ABLATE 0 // experiments only: 1 no CN writes, 2 no CN S reads, 4 no barriers, 8 no CN R reads, 16 no VN reads, 32 no VN writes
+#endif
+
 namespace cldpc {
 
 struct QcCnEdge { unsigned short col, shift; };  // block-row-major list of non-zero blocks
-struct QcVnEdge { unsigned short e, shift; };    // per column, top->bottom: block index e into the CN list
+struct QcVnEdge { unsigned short e, shift; };    // per column, top->bottom: padded block index row*WC+position
 
 struct QcArgs {
-    const float *y;             // [N][F]
-    int *D;                     // [N+1][F]
+    const float *y;             // [ceil(F/NF)][N][NF]  channel values regrouped per workgroup (k_regroup_y)
+    int *D;                     // [N+1][F]  (the kernel itself writes only the flag row N)
+    unsigned *bits;             // [F][N/32] packed hard bits
     float *app;                 // [N][F] or nullptr
     unsigned long long *hist;   // [F] flag history or nullptr
     const QcCnEdge *cn_edges;   // [nnz]
     const unsigned short *rowptr; // [J+1]
     const QcVnEdge *vn_edges;   // [L][WV]
     const unsigned char *wv;    // [L]
-    int J, L, Z, F, FP, G, U, nWG, max_iter, length, nnz;
+    int F, nWG, max_iter, length;
 };
 
 template <int NF> struct Msg;
 template <> struct Msg<1> { using T = float; };
-template <> struct Msg<2> { using T = float2; };
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+template <> struct Msg<2> { using T = v2f32; };
 
-template <int NF> __device__ __forceinline__ void lds_ld(float (&d)[NF], const float *lds, int idx)
+// LDS access of one message (NF floats) by absolute LDS byte address.  The kernel owns all of its LDS
+// through the dynamic segment and declares no static __shared__ object, so that segment starts at LDS
+// address 0; addressing it with plain integers (address space 3) avoids the `v_add base, offset` the
+// compiler otherwise emits in front of every ds_ instruction for the (link-time) segment base.
+typedef __attribute__((address_space(3))) char lds_char;
+template <int NF> __device__ __forceinline__ void lds_ld(float (&d)[NF], const char *, int byte_off)
 {
-    typename Msg<NF>::T v = *reinterpret_cast<const typename Msg<NF>::T *>(lds + idx);
+    typedef __attribute__((address_space(3))) const typename Msg<NF>::T lds_msg;
+    typename Msg<NF>::T v = *reinterpret_cast<lds_msg *>(static_cast<unsigned>(byte_off));
     __builtin_memcpy(d, &v, sizeof(v));
 }
-template <int NF> __device__ __forceinline__ void lds_st(float *lds, int idx, const float (&s)[NF])
+template <int NF> __device__ __forceinline__ void lds_st(char *, int byte_off, const float (&s)[NF])
 {
+    typedef __attribute__((address_space(3))) typename Msg<NF>::T lds_msg;
     typename Msg<NF>::T v;
     __builtin_memcpy(&v, s, sizeof(v));
-    *reinterpret_cast<typename Msg<NF>::T *>(lds + idx) = v;
+    *reinterpret_cast<lds_msg *>(static_cast<unsigned>(byte_off)) = v;
 }
 
-// Packed pairs of 16-bit LDS slot indices (one slot = NF floats); halves the address registers.
-template <int NF> __device__ __forceinline__ int slot_lo(unsigned pk) { return (int)(pk & 0xffffu) * NF; }
-template <int NF> __device__ __forceinline__ int slot_hi(unsigned pk) { return (int)(pk >> 16) * NF; }
+// Compile-time geometry of one kernel variant: G*Z threads decode NF frames.
+template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int G_, int MINW_> struct QcGeom {
+    static constexpr int NF = NF_, J = J_, L = L_, Z = Z_, WC = WC_, WV = WV_, G = G_, MINW = MINW_;
+    static constexpr int RPT = (J + G - 1) / G, CPT = (L + G - 1) / G, TPB = G * Z;
+    static constexpr int MSG = NF * 4;              // bytes per message slot
+    static constexpr int Sslot = J * WC * Z;        // R blocks (row-padded to WC), then S columns
+    static constexpr int zero_slot = Sslot + L * Z; // always +0.0f
+    static constexpr int inf_slot = zero_slot + 1;  // always +inf
+    static constexpr int flag_byte = (inf_slot + 1) * MSG;
+    static constexpr int lds_bytes = flag_byte + NF * 4;
+    static constexpr int NW = (L * Z) / 32;         // 32-bit words of hard bits per frame
+    static_assert(TPB % 64 == 0 && TPB <= 1024, "workgroup must be whole waves");
+    static_assert(Z % 32 == 0, "half-waves must not straddle a thread group");
+    static_assert(J % G == 0 && L % G == 0, "groups must tile the block rows and columns");
+    static_assert(inf_slot < 65536, "slot indices are packed into 16 bits");
+};
 
-// NF frames per lane, RPT check rows per thread (max), WC max row weight,
-// CPT variable columns per thread (max), WV max column weight, TPB threads per workgroup,
-// HIST: record the per-iteration termination flags (flag history / batch-global exit).
-//
-// The iteration loop is branch-free below row/column granularity: rows lighter than WC are padded
-// with dummy edges that read a +inf slot (neutral for min1/min2/sign) and write into the row's own
-// padding blocks; columns lighter than WV read a slot that always holds +0.0f (adding +0.0f to a sum
-// that is never -0.0f is exact), so the compiler can keep all LDS reads of a phase in flight.
-template <int NF, int RPT, int WC, int CPT, int WV, int TPB, bool HIST>
-__global__ __launch_bounds__(TPB) void k_qc(QcArgs a)
+// Thread tid = g*Z + t owns check rows (j, t), j = g + rr*G and variables (l, t), l = g + cc*G.
+// g is NOT wave-uniform (Z need not be a multiple of 64): nothing in the iteration loop depends on g
+// except per-lane base addresses, so no lane ever idles; the per-edge tables are gathered per lane,
+// once, in the prologue.
+template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc(QcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NF = GM::NF, J = GM::J, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, G = GM::G;
+    constexpr int RPT = GM::RPT, CPT = GM::CPT, MSG = GM::MSG;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-aware workgroup id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
-    // contiguous range of frames so the 4-byte-per-frame rows of y / D are completed in one L2.
+    // contiguous range of frames so the 4-byte-per-frame rows of y are fetched into one L2 only.
     const int chunk = (a.nWG + 7) >> 3;
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (wg >= a.nWG) return;
 
-    const int Z = a.Z, FP = a.FP, G = a.G, U = a.U, F = a.F;
+    const int F = a.F;
     const int tid = threadIdx.x;
-    const int g = __builtin_amdgcn_readfirstlane(tid / U); // wave-uniform (U % 64 == 0)
-    const int u = tid - g * U;
-    const int p = u / Z, t = u - p * Z;
-    const int f0 = (wg * FP + p) * NF;      // first frame carried by this lane
-    const int strideS = FP * Z;              // slots between consecutive blocks / columns
-    const int lane_slot = p * Z + t;         // aligned position of this lane inside a block
-    const int Sslot = a.J * WC * strideS;    // Rbuf: J rows x WC blocks (row-padded), then Sbuf: L columns
-    const int zero_slot = Sslot + a.L * strideS; // always +0.0f
-    const int inf_slot = zero_slot + 1;          // always +inf
-    const int trash_slot = inf_slot + 1;         // one block: S of padding columns (l >= L) lands here
-    int *lds_flag = reinterpret_cast<int *>(lds + (trash_slot + strideS) * NF); // [FP*NF]
+    const int g = tid / Z, t = tid - g * Z;
+    const int f0 = wg * NF; // first frame of this workgroup
+    int *lds_flag = reinterpret_cast<int *>(lds + GM::flag_byte); // [NF]
 
-    // ---- prologue: per-thread edge addresses, channel values, zeroed R ------------------
-    float Rreg[RPT][WC][NF];
-    unsigned saddr[RPT][(WC + 1) / 2];
-    int rbase[RPT];
-    bool rvalid[RPT];
+    // ---- prologue: rotated slot indices, channel values, zeroed R ----------------------------
+    // row j = g + rr*G, block pp:   R slot  (j*WC + pp)*Z + t               (aligned)
+    //                               S slot  Sslot + col*Z + (t+s) mod Z     (rotated)
+    const int rbase = (g * WC * Z + t) * MSG;          // + (rr*G*WC + pp)*Z*MSG as immediate offsets
+    const int sbase = (GM::Sslot + g * Z + t) * MSG;   // + cc*G*Z*MSG
+    unsigned saddr[RPT][(WC + 1) / 2];                 // S slots of the row's neighbours, packed 2 x 16 bit
+    // All table gathers are issued unconditionally (index clamped into the row / column) and only then
+    // consumed: predicated loads would be waited for one by one, ~0.4 us each under load.
+    int e0v[RPT], wrv[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
-        const int j = g + rr * G;
-        rvalid[rr] = j < a.J;
-        rbase[rr] = (j * WC * strideS + lane_slot) * NF;
-        const int e0 = rvalid[rr] ? a.rowptr[j] : 0;
-        const int w = rvalid[rr] ? a.rowptr[j + 1] - e0 : 0;
+        e0v[rr] = a.rowptr[g + rr * G];
+        wrv[rr] = a.rowptr[g + rr * G + 1] - e0v[rr];
+    }
+    int wcv[CPT];
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) wcv[cc] = a.wv[g + cc * G];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+        QcCnEdge ed[WC];
+#pragma unroll
+        for (int pp = 0; pp < WC; pp++) ed[pp] = a.cn_edges[e0v[rr] + min(pp, wrv[rr] - 1)];
 #pragma unroll
         for (int pp = 0; pp < WC; pp++) {
-            int slot = inf_slot;
-            if (pp < w) {
-                const QcCnEdge ed = a.cn_edges[e0 + pp];
-                int c = t + ed.shift;
-                c = (c >= Z) ? c - Z : c;
-                slot = Sslot + ed.col * strideS + p * Z + c;
-            }
+            int c = t + ed[pp].shift;
+            c = (c >= Z) ? c - Z : c;
+            const int slot = (pp < wrv[rr]) ? GM::Sslot + ed[pp].col * Z + c : GM::inf_slot;
             if (pp & 1) saddr[rr][pp / 2] |= (unsigned)slot << 16;
             else saddr[rr][pp / 2] = (unsigned)slot;
-#pragma unroll
-            for (int v = 0; v < NF; v++) Rreg[rr][pp][v] = 0.0f;
-            if (rvalid[rr]) {
-                const float zero[NF] = {};
-                lds_st<NF>(lds, rbase[rr] + pp * strideS * NF, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
-            }
+            const float zero[NF] = {};
+            lds_st<NF>(lds, rbase + (rr * G * WC + pp) * Z * MSG, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
         }
     }
     float yreg[CPT][NF];
-    unsigned raddr[CPT][(WV + 1) / 2];
-    bool cvalid[CPT];
-    int swrite[CPT]; // float index of this lane's S slot per column (trash block for padding columns)
+    int raddr[CPT][WV]; // byte addresses of the R messages of each variable's edges
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
         const int l = g + cc * G;
-        cvalid[cc] = l < a.L;
-        const int w = cvalid[cc] ? a.wv[l] : 0;
-        swrite[cc] = ((cvalid[cc] ? Sslot + l * strideS : trash_slot) + lane_slot) * NF;
+        QcVnEdge ed[WV];
 #pragma unroll
-        for (int k = 0; k < WV; k++) {
-            int slot = zero_slot;
-            if (k < w) {
-                const QcVnEdge ed = a.vn_edges[l * WV + k]; // ed.e = row * WC + position
-                int r = t - ed.shift;
-                r = (r < 0) ? r + Z : r;
-                slot = ed.e * strideS + p * Z + r;
-            }
-            if (k & 1) raddr[cc][k / 2] |= (unsigned)slot << 16;
-            else raddr[cc][k / 2] = (unsigned)slot;
+        for (int k = 0; k < WV; k++) ed[k] = a.vn_edges[l * WV + min(k, wcv[cc] - 1)];
+        {   // one coalesced NF*4-byte load per lane (frames >= F were zero-filled by k_regroup_y)
+            typename Msg<NF>::T yv = *reinterpret_cast<const typename Msg<NF>::T *>(a.y + ((size_t)wg * (L * Z) + l * Z + t) * NF);
+            __builtin_memcpy(yreg[cc], &yv, sizeof(yv));
         }
 #pragma unroll
-        for (int v = 0; v < NF; v++) {
-            yreg[cc][v] = 0.0f;
-            if (cvalid[cc] && f0 + v < F) yreg[cc][v] = a.y[(size_t)(l * Z + t) * F + f0 + v];
+        for (int k = 0; k < WV; k++) {
+            int r = t - ed[k].shift;
+            r = (r < 0) ? r + Z : r;
+            raddr[cc][k] = ((k < wcv[cc]) ? ed[k].e * Z + r : GM::zero_slot) * MSG;
         }
     }
     if (tid < NF) {
-        lds[zero_slot * NF + tid] = 0.0f;
-        lds[inf_slot * NF + tid] = __builtin_inff();
+        reinterpret_cast<float *>(lds)[GM::zero_slot * NF + tid] = 0.0f;
+        reinterpret_cast<float *>(lds)[GM::inf_slot * NF + tid] = __builtin_inff();
+        lds_flag[tid] = 0;
     }
-    if (tid < FP * NF) lds_flag[tid] = 0;
-    unsigned long long hist = 0; // used by threads tid < FP*NF
+    unsigned long long hist = 0; // used by threads tid < NF
     __syncthreads();
 
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
     auto vn_phase = [&](bool (&bad)[NF]) {
-        float R[CPT][WV][NF];
+        constexpr int CB = (CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1); // columns with reads in flight together
 #pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
+        for (int c0 = 0; c0 < CPT; c0 += CB) {
+            float R[CB][WV][NF];
 #pragma unroll
-            for (int k = 0; k < WV; k++)
-                lds_ld<NF>(R[cc][k], lds, (k & 1) ? slot_hi<NF>(raddr[cc][k / 2]) : slot_lo<NF>(raddr[cc][k / 2]));
-        }
+            for (int ci = 0; ci < CB; ci++)
 #pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            float S[NF];
+                for (int k = 0; k < WV; k++) lds_ld<NF>(R[ci][k], lds, raddr[c0 + ci][k]);
 #pragma unroll
-            for (int v = 0; v < NF; v++) S[v] = 0.0f;
+            for (int ci = 0; ci < CB; ci++) {
+                const int cc = c0 + ci;
+                float S[NF];
 #pragma unroll
-            for (int k = 0; k < WV; k++) {
+                for (int v = 0; v < NF; v++) S[v] = 0.0f;
 #pragma unroll
-                for (int v = 0; v < NF; v++) S[v] += R[cc][k][v];
+                for (int k = 0; k < WV; k++) {
+#pragma unroll
+                    for (int v = 0; v < NF; v++) S[v] += R[ci][k][v];
+                }
+#pragma unroll
+                for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
+                lds_st<NF>(lds, sbase + cc * G * Z * MSG, S);
+                if (HIST) {
+                    const bool in_len = ((g + cc * G) * Z + t) < a.length;
+#pragma unroll
+                    for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
+                }
             }
-#pragma unroll
-            for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
-            lds_st<NF>(lds, swrite[cc], S);
-            if (HIST) {
-                const bool in_len = cvalid[cc] && ((g + cc * G) * Z + t) < a.length;
-#pragma unroll
-                for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147); call between VN phase and barrier / after it
+    // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147)
     auto flags_publish = [&](const bool (&bad)[NF]) {
 #pragma unroll
         for (int v = 0; v < NF; v++)
-            if (bad[v]) lds_flag[p * NF + v] = 1; // same value from every writer
+            if (bad[v]) lds_flag[v] = 1; // same value from every writer
     };
     auto flags_collect = [&](int it) -> int {
         int flag = 0;
-        if (tid < FP * NF) {
+        if (tid < NF) {
             flag = lds_flag[tid] ? 0 : 1;
             lds_flag[tid] = 0;
             if (flag && it <= 64) hist |= (1ull << (it - 1));
@@ -215,59 +236,68 @@ __global__ __launch_bounds__(TPB) void k_qc(QcArgs a)
         return flag;
     };
 
-    // ---- iterations 1 .. max_iter-1: VN, CN ----------------------------------------------
+    // ---- iterations 1 .. max_iter-1: VN, CN --------------------------------------------------
     for (int it = 1; it < a.max_iter; it++) {
-        // keep the 16-bit-packed slot indices packed across iterations (the unpacked form costs 2x the VGPRs)
+        // keep the 16-bit-packed slot indices packed across iterations (unpacked they cost 2x the VGPRs)
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
             for (int i = 0; i < (WC + 1) / 2; i++) asm volatile("" : "+v"(saddr[rr][i]));
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++)
-#pragma unroll
-            for (int i = 0; i < (WV + 1) / 2; i++) asm volatile("" : "+v"(raddr[cc][i]));
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
         vn_phase(bad);
         if (HIST) flags_publish(bad);
-        __syncthreads();
+        if (!(QC_ABLATE & 4)) __syncthreads();
         if (HIST) (void)flags_collect(it);
 
         // CN phase (LDPC_Decoder.cu:279-314)
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
-            if (rvalid[rr]) {
-                float Q[WC][NF];
+            // CH: edges whose S and R reads are in flight together (bounds VGPR use)
+            constexpr int CH = (WC % 5 == 0) ? 5 : ((WC % 4 == 0) ? 4 : ((WC % 7 == 0) ? 7 : WC));
+            float Q[WC][NF];
+            CnAcc acc[NF];
 #pragma unroll
-                for (int pp = 0; pp < WC; pp++)
-                    lds_ld<NF>(Q[pp], lds, (pp & 1) ? slot_hi<NF>(saddr[rr][pp / 2]) : slot_lo<NF>(saddr[rr][pp / 2]));
-                CnAcc acc[NF];
+            for (int v = 0; v < NF; v++) acc[v].init();
 #pragma unroll
-                for (int v = 0; v < NF; v++) acc[v].init();
+            for (int p0 = 0; p0 < WC; p0 += CH) {
+                float Sv[CH][NF], Rv[CH][NF];
 #pragma unroll
-                for (int pp = 0; pp < WC; pp++) {
+                for (int i = 0; i < CH; i++) {
+                    const int pp = p0 + i;
+                    const unsigned pk = saddr[rr][pp / 2];
+                    if (!(QC_ABLATE & 2)) lds_ld<NF>(Sv[i], lds, (int)((pp & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
+                    else { for (int v = 0; v < NF; v++) Sv[i][v] = __uint_as_float(pk + pp + it); }
+                    if (!(QC_ABLATE & 8)) lds_ld<NF>(Rv[i], lds, rbase + (rr * G * WC + pp) * Z * MSG);
+                    else { for (int v = 0; v < NF; v++) Rv[i][v] = __uint_as_float(pk * 3 + pp); }
+                }
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
 #pragma unroll
                     for (int v = 0; v < NF; v++) {
-                        Q[pp][v] = Q[pp][v] - Rreg[rr][pp][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
-                        acc[v].add(Q[pp][v]);
+                        Q[p0 + i][v] = Sv[i][v] - Rv[i][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
+                        acc[v].add(Q[p0 + i][v]);
                     }
                 }
-                uint32_t key[NF];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint32_t key[NF];
 #pragma unroll
-                for (int v = 0; v < NF; v++) key[v] = acc[v].key();
+            for (int v = 0; v < NF; v++) key[v] = acc[v].key();
 #pragma unroll
-                for (int pp = 0; pp < WC; pp++) {
+            for (int pp = 0; pp < WC; pp++) {
+                float Rn[NF];
 #pragma unroll
-                    for (int v = 0; v < NF; v++) Rreg[rr][pp][v] = cn_out(Q[pp][v], acc[v].m2, key[v]);
-                    lds_st<NF>(lds, rbase[rr] + pp * strideS * NF, Rreg[rr][pp]);
-                }
+                for (int v = 0; v < NF; v++) Rn[v] = cn_out(Q[pp][v], acc[v].m2, key[v]);
+                if (!(QC_ABLATE & 1)) lds_st<NF>(lds, rbase + (rr * G * WC + pp) * Z * MSG, Rn);
+                else if (Rn[0] == 1.2345f) lds_st<NF>(lds, rbase, Rn);
             }
         }
-        __syncthreads();
+        if (!(QC_ABLATE & 4)) __syncthreads();
     }
 
-    // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -------
+    // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -----------
     {
         bool bad[NF];
 #pragma unroll
@@ -275,28 +305,79 @@ __global__ __launch_bounds__(TPB) void k_qc(QcArgs a)
         vn_phase(bad);
 #pragma unroll
         for (int cc = 0; cc < CPT; cc++) {
-            if (cvalid[cc]) {
-                const int n = (g + cc * G) * Z + t;
-                float S[NF];
-                lds_ld<NF>(S, lds, swrite[cc]); // own value, just written
+            const int n = (g + cc * G) * Z + t;
+            float S[NF];
+            lds_ld<NF>(S, lds, sbase + cc * G * Z * MSG); // own value, just written
 #pragma unroll
-                for (int v = 0; v < NF; v++) {
-                    if (!HIST) bad[v] = bad[v] || (n < a.length && S[v] < 0);
-                    if (f0 + v < F) {
-                        a.D[(size_t)n * F + f0 + v] = (S[v] < 0) ? 1 : 0;
-                        if (a.app) a.app[(size_t)n * F + f0 + v] = S[v];
-                    }
-                }
+            for (int v = 0; v < NF; v++) {
+                const bool neg = S[v] < 0;
+                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
+                // hard bits leave packed, one 32-bit word per half-wave: Z % 32 == 0 keeps the 32 lanes of a
+                // half-wave inside one thread group, i.e. on 32 consecutive variables n .. n+31, n % 32 == 0.
+                const unsigned long long m = __ballot(neg);
+                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
             }
         }
         flags_publish(bad);
         __syncthreads();
         const int flag = flags_collect(a.max_iter);
-        const int f = wg * FP * NF + tid;
-        if (tid < FP * NF && f < F) {
-            a.D[(size_t)a.L * Z * F + f] = flag;
-            if (HIST && a.hist) a.hist[f] = hist;
+        if (tid < NF && f0 + tid < F) {
+            a.D[(size_t)L * Z * F + f0 + tid] = flag;
+            if (HIST && a.hist) a.hist[f0 + tid] = hist;
         }
+    }
+}
+
+// Regroup the reference's frame-fastest Channel_Out [N][F] into per-workgroup slabs [F/NF][N][NF] so that the
+// decode kernel's loads are contiguous along the circulant dimension (the reference layout would cost every
+// lane its own 128-byte line for 4*NF useful bytes).  64 x 64 tiles through LDS; reads and writes coalesced.
+template <int NF> __global__ __launch_bounds__(256) void k_regroup_y(const float *y, float *out, int N, int F)
+{
+    __shared__ float tile[64][65];
+    const int f0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int n = n0 + i * 4 + w, f = f0 + lane;
+        tile[i * 4 + w][lane] = (n < N && f < F) ? y[(size_t)n * F + f] : 0.0f;
+    }
+    __syncthreads();
+    const int n = n0 + lane;
+    for (int q = w; q < 64 / NF; q += 4) { // q-th frame group of this tile
+        const int fg = f0 / NF + q;
+        if (n < N && fg * NF < F + NF - 1 && fg < (F + NF - 1) / NF) {
+            float v[NF];
+#pragma unroll
+            for (int k = 0; k < NF; k++) v[k] = tile[lane][q * NF + k];
+            typename Msg<NF>::T o;
+            __builtin_memcpy(&o, v, sizeof(o));
+            *reinterpret_cast<typename Msg<NF>::T *>(out + ((size_t)fg * N + n) * NF) = o;
+        }
+    }
+}
+
+// Unpack the hard bits into the reference's D layout (int32 [N][F], frame-fastest): one thread per
+// (word w, 4 frames); reads 4 words, writes 32 rows of int4 -- stores coalesce along the frame dimension.
+__global__ __launch_bounds__(256) void k_expand_bits(const unsigned *bits, int *D, int F, int NW)
+{
+    const int f = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int w = blockIdx.y;
+    if (f >= F) return;
+    unsigned x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = (f + i < F) ? bits[(size_t)(f + i) * NW + w] : 0u;
+    int *row = D + (size_t)w * 32 * F + f;
+    if (f + 3 < F && (F & 3) == 0) {
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            int4 o;
+            o.x = (x[0] >> b) & 1; o.y = (x[1] >> b) & 1; o.z = (x[2] >> b) & 1; o.w = (x[3] >> b) & 1;
+            *reinterpret_cast<int4 *>(row + (size_t)b * F) = o;
+        }
+    } else {
+        for (int b = 0; b < 32; b++)
+            for (int i = 0; i < 4 && f + i < F; i++) row[(size_t)b * F + i] = (x[i] >> b) & 1;
     }
 }
 
@@ -310,35 +391,27 @@ __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist
 }
 
 // ---------------------------------------------------------------------------------------------
-struct QcPlan {
-    int J = 0, L = 0, Z = 0, nnz = 0, Wc = 0, Wv = 0;
-    int NF = 0, FP = 0, G = 0, U = 0, RPT = 0, CPT = 0, threads = 0, variant = -1;
-    int frames_per_wg = 0; // 0 = unavailable
-    size_t lds_bytes = 0;
-    QcCnEdge *d_cn = nullptr;
-    unsigned short *d_rowptr = nullptr;
-    QcVnEdge *d_vn = nullptr;
-    unsigned char *d_wv = nullptr;
-    char name[64] = "qc_lds(unavailable)";
-};
-
 using QcKernel = void (*)(QcArgs);
-struct QcVariant { int NF, RPT, WC, CPT, WV, TPB; QcKernel fn, fn_hist; };
+struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; };
 
-// Ahead-of-time instantiations.  A code runs on the first variant whose bounds
-// cover it; codes outside all of them use the table kernels.
-//                                   NF RPT WC CPT WV  TPB
-#define QC_VARIANTS(X)             \
-    X(2, 1, 20, 6, 4, 768)         /* J4_L24_Z96 (BASELINE config 2)      */ \
-    X(2, 2, 7, 4, 3, 1024)         /* J32_L64_Z64 (BASELINE config 3)     */ \
-    X(2, 2, 10, 6, 6, 768)         /* J8_L24_Z96                          */ \
-    X(2, 3, 7, 6, 6, 768)          /* J12_L24_Z96                         */ \
-    X(1, 2, 15, 8, 4, 768)         /* J6_L24_Z96 (one frame per lane)     */ \
-    X(1, 1, 20, 6, 4, 1024)        /* J4_L24_Z256 (one frame per lane)    */
+// Ahead-of-time variants: one per block-matrix geometry of the reference's matrix set whose message
+// state fits one CU's LDS (shifts are run-time data, so every code of the same J x L x Z shape and
+// weights <= WC/WV shares a variant).  Everything else runs on the table kernels.
+//        NF   J   L    Z  WC WV   G MINW
+#define QC_VARIANTS(X)                                                                          \
+    X(2,   4, 24,  96, 20, 4,  4, 4) /* J4_L24_Z96 (BASELINE config 2): 384 thr, 81 KB, 2 WG/CU */ \
+    X(2,  32, 64,  64,  7, 3, 16, 4) /* J32_L64_Z64 (BASELINE config 3): 1024 thr, 148 KB       */ \
+    X(2,   8, 24,  96, 10, 6,  4, 3) /* J8_L24_Z96                                              */ \
+    X(2,  12, 24,  96,  7, 6,  6, 2) /* J12_L24_Z96                                             */ \
+    X(2,   6, 24,  96, 15, 4,  6, 2) /* J6_L24_Z96                                              */ \
+    X(1,   4, 24, 256, 20, 4,  4, 4) /* J4_L24_Z256 (one frame per lane)                        */
 
 inline const QcVariant *qc_variants(int *count)
 {
-#define X(NF, RPT, WC, CPT, WV, TPB) {NF, RPT, WC, CPT, WV, TPB, k_qc<NF, RPT, WC, CPT, WV, TPB, false>, k_qc<NF, RPT, WC, CPT, WV, TPB, true>},
+#define X(NF, J, L, Z, WC, WV, G, MINW)                                                                  \
+    {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW>::TPB,                              \
+     QcGeom<NF, J, L, Z, WC, WV, G, MINW>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, false>,    \
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>},
     static const QcVariant v[] = {QC_VARIANTS(X)};
 #undef X
     *count = (int)(sizeof(v) / sizeof(v[0]));
@@ -346,6 +419,17 @@ inline const QcVariant *qc_variants(int *count)
 }
 
 constexpr size_t kLdsBytes = 160 * 1024;
+
+struct QcPlan {
+    int J = 0, L = 0, Z = 0, nnz = 0, Wc = 0, Wv = 0;
+    int variant = -1;
+    int frames_per_wg = 0; // 0 = unavailable
+    QcCnEdge *d_cn = nullptr;
+    unsigned short *d_rowptr = nullptr;
+    QcVnEdge *d_vn = nullptr;
+    unsigned char *d_wv = nullptr;
+    char name[96] = "qc_lds(unavailable)";
+};
 
 inline void qc_plan_release(QcPlan *q)
 {
@@ -357,10 +441,8 @@ inline void qc_plan_release(QcPlan *q)
     q->frames_per_wg = 0;
 }
 
-static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
-
-// Choose (NF, FP, G, variant) for the code, upload its block lists.  Leaves
-// frames_per_wg == 0 (not an error) when no variant / LDS budget fits.
+// Pick the first variant whose geometry matches the code, upload its block lists.  Leaves
+// frames_per_wg == 0 (not an error) when none does.  BLDPC_QC_VARIANT=<index> pins one (experiments).
 inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
 {
     q->J = J; q->L = L; q->Z = Z;
@@ -382,28 +464,17 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     const int nnz = (int)cn.size();
     const int Wv = *std::max_element(wv.begin(), wv.end());
     q->nnz = nnz; q->Wc = Wc; q->Wv = Wv;
-    const int FPmin = 64 / gcd_i(Z, 64);
     int nvar = 0;
     const QcVariant *vars = qc_variants(&nvar);
-    for (int NF = 2; NF >= 1 && q->frames_per_wg == 0; NF--) {
-        const int FP = FPmin, U = FP * Z;
-        if (U > 1024) continue;
-        for (int vi = 0; vi < nvar && q->frames_per_wg == 0; vi++) {
-            const QcVariant &v = vars[vi];
-            if (v.NF != NF || v.WC < Wc || v.WV < Wv) continue;
-            // LDS: R blocks (J rows padded to the variant's WC), S columns, the +0 / +inf slots, the flags
-            const size_t slots = (size_t)(J * v.WC + L + 1) * U + 2; // + one trash block
-            const size_t lds = (slots * NF + FP * NF) * sizeof(float);
-            if (lds > kLdsBytes || slots > 65535) continue; // slot indices are packed into 16 bits
-            const int G = std::min(v.TPB / U, std::max(J, 1));
-            if (G < 1) continue;
-            const int RPT = (J + G - 1) / G, CPT = (L + G - 1) / G;
-            if (RPT > v.RPT || CPT > v.CPT) continue;
-            q->NF = NF; q->FP = FP; q->U = U; q->G = G; q->RPT = RPT; q->CPT = CPT;
-            q->threads = G * U; q->variant = vi; q->lds_bytes = lds; q->frames_per_wg = NF * FP;
-        }
+    const char *pin = getenv("BLDPC_QC_VARIANT");
+    for (int vi = 0; vi < nvar && q->variant < 0; vi++) {
+        const QcVariant &v = vars[vi];
+        if (pin && atoi(pin) != vi) continue;
+        if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.WV < Wv) continue;
+        if ((size_t)v.lds_bytes > kLdsBytes) continue;
+        q->variant = vi;
     }
-    if (q->frames_per_wg == 0) return BLDPC_OK;
+    if (q->variant < 0) return BLDPC_OK;
     const QcVariant &v = vars[q->variant];
     std::vector<QcVnEdge> vn((size_t)L * v.WV, QcVnEdge{0, 0});
     std::vector<int> fill(L, 0);
@@ -423,45 +494,67 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     CLDPC_HIP(hipMemcpy(q->d_rowptr, rowptr.data(), rowptr.size() * sizeof(unsigned short), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipMemcpy(q->d_vn, vn.data(), vn.size() * sizeof(QcVnEdge), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipMemcpy(q->d_wv, wvb.data(), wvb.size(), hipMemcpyHostToDevice), BLDPC_EHIP);
-    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes), BLDPC_EHIP);
-    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes), BLDPC_EHIP);
-    snprintf(q->name, sizeof(q->name), "qc_lds<nf%d,rpt%d,wc%d,cpt%d,wv%d>g%d_fp%d_t%d", v.NF, v.RPT, v.WC, v.CPT, v.WV, q->G, q->FP,
-             q->threads);
+    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
+    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
+    q->frames_per_wg = v.NF;
+    snprintf(q->name, sizeof(q->name), "qc_lds<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.NF, v.J, v.L, v.Z, v.WC, v.WV, v.G,
+             v.MINW, v.threads, v.lds_bytes);
     return BLDPC_OK;
 }
 
-inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
-                     unsigned long long *hist, hipStream_t st)
+inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStream_t st)
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
-    QcArgs a;
-    a.y = y; a.D = D; a.app = app; a.hist = hist;
-    a.cn_edges = q->d_cn; a.rowptr = q->d_rowptr; a.vn_edges = q->d_vn; a.wv = q->d_wv;
-    a.J = q->J; a.L = q->L; a.Z = q->Z; a.F = F; a.FP = q->FP; a.G = q->G; a.U = q->U;
-    a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
-    a.max_iter = max_iter; a.length = length; a.nnz = q->nnz;
-    const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
-    hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(q->threads), q->lds_bytes, st, a);
+    const int N = v.L * v.Z;
+    const dim3 grid((unsigned)((F + 63) / 64), (unsigned)((N + 63) / 64));
+    if (v.NF == 2) hipLaunchKernelGGL(k_regroup_y<2>, grid, dim3(256), 0, st, y, yg, N, F);
+    else hipLaunchKernelGGL(k_regroup_y<1>, grid, dim3(256), 0, st, y, yg, N, F);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
 }
 
-// hist_ws: device uint64[F] workspace; and_ws: device uint64; h_word: pinned host int[>=2].
-inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
-                     unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, int *h_word,
-                     int *itera, hipStream_t st)
+// y here is the regrouped buffer produced by qc_regroup.
+inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
+                     unsigned long long *hist, unsigned *bits, hipStream_t st)
 {
+    int nvar = 0;
+    const QcVariant &v = qc_variants(&nvar)[q->variant];
+    QcArgs a;
+    a.y = y; a.D = D; a.bits = bits; a.app = app; a.hist = hist;
+    a.cn_edges = q->d_cn; a.rowptr = q->d_rowptr; a.vn_edges = q->d_vn; a.wv = q->d_wv;
+    a.F = F;
+    a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
+    a.max_iter = max_iter; a.length = length;
+    const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
+    hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), v.lds_bytes, st, a);
+    const int NW = v.L * v.Z / 32;
+    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW);
+    CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
+    return BLDPC_OK;
+}
+
+// hist_ws: device uint64[F] workspace; and_ws: device uint64; bits: device uint32 [F][N/32] workspace;
+// yg: device float [ceil(F/NF)*NF][N] workspace for the regrouped channel values.
+inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
+                     unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, unsigned *bits,
+                     float *yg, int *itera, hipStream_t st)
+{
+    {
+        int rr = qc_regroup(q, y, yg, F, st);
+        if (rr) return rr;
+        y = yg;
+    }
     if (exit_mode == BLDPC_EXIT_FIXED) {
         *itera = max_iter;
-        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, st);
+        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, bits, st);
     }
     // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are
     // flagged.  Pass 1 runs max_iter iterations on-chip recording each frame's flag history; the AND of
     // the histories gives that iteration; if it is earlier than max_iter, pass 2 replays exactly that many.
     if (max_iter > 64) return fail(BLDPC_EUNSUPPORTED, "QC_LDS with BATCH_GLOBAL exit supports max_iter <= 64 (got %d)", max_iter);
     unsigned long long *hist = flag_hist ? flag_hist : hist_ws;
-    int r = qc_launch(q, y, F, max_iter, length, D, app, hist, st);
+    int r = qc_launch(q, y, F, max_iter, length, D, app, hist, bits, st);
     if (r) return r;
     const unsigned long long ones = ~0ull;
     CLDPC_HIP(hipMemcpyAsync(and_ws, &ones, sizeof(ones), hipMemcpyHostToDevice, st), BLDPC_EHIP);
@@ -469,12 +562,11 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     unsigned long long all = 0;
     CLDPC_HIP(hipMemcpyAsync(&all, and_ws, sizeof(all), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
     CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
-    (void)h_word;
     if (max_iter < 64) all &= ((1ull << max_iter) - 1);
     int stop = max_iter;
     if (all) stop = __builtin_ctzll(all) + 1;
     *itera = stop;
-    if (stop < max_iter) return qc_launch(q, y, F, stop, length, D, app, flag_hist, st);
+    if (stop < max_iter) return qc_launch(q, y, F, stop, length, D, app, flag_hist, bits, st);
     return BLDPC_OK;
 }
 

@@ -160,27 +160,43 @@ __global__ __launch_bounds__(256) void k_flags(int *bad, int *D_flag_row, unsign
     }
 }
 
-// Device-side Statistic (Simulation.cu:245-262): one thread per frame.
-__global__ __launch_bounds__(256) void k_statistic(const int *D, const int *cw, int N, int F, int length, int itera,
-                                                   long long *counters)
+// Device-side Statistic (Simulation.cu:245-262), two stages so that the N*F-word read of D streams at HBM
+// rate: stage 1 counts message-bit errors per frame over a slice of rows (4 frames per lane, 16-byte loads,
+// one atomic per frame and slice), stage 2 classifies each frame and reduces the five counters.
+__global__ __launch_bounds__(256) void k_stat_errors(const int *D, const int *cw, int F, int length, int rows_per_slice, int *errs)
+{
+    const int f = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (f >= F) return;
+    const int k0 = blockIdx.y * rows_per_slice, k1 = min(length, k0 + rows_per_slice);
+    int e[4] = {0, 0, 0, 0};
+    if (f + 3 < F && (F & 3) == 0) {
+        for (int k = k0; k < k1; k++) {
+            const int4 d = *reinterpret_cast<const int4 *>(D + (size_t)k * F + f);
+            int4 c = make_int4(0, 0, 0, 0);
+            if (cw) c = *reinterpret_cast<const int4 *>(cw + (size_t)k * F + f);
+            e[0] += d.x != c.x; e[1] += d.y != c.y; e[2] += d.z != c.z; e[3] += d.w != c.w;
+        }
+    } else {
+        for (int k = k0; k < k1; k++)
+            for (int i = 0; i < 4 && f + i < F; i++) e[i] += D[(size_t)k * F + f + i] != (cw ? cw[(size_t)k * F + f + i] : 0);
+    }
+    for (int i = 0; i < 4 && f + i < F; i++)
+        if (e[i]) atomicAdd(&errs[f + i], e[i]);
+}
+
+__global__ __launch_bounds__(256) void k_stat_final(int *errs, const int *flag_row, int F, int itera, long long *counters)
 {
     const int f = blockIdx.x * 256 + threadIdx.x;
-    long long err_frames = 0, err_bits = 0, its = 0, fals = 0, alarm = 0;
+    long long v[5] = {0, 0, 0, 0, 0};
     if (f < F) {
-        int err = 0;
-        for (int k = 0; k < length; k++) {
-            int c = cw ? cw[(size_t)k * F + f] : 0;
-            err += (D[(size_t)k * F + f] != c) ? 1 : 0;
-        }
-        const int flag = D[(size_t)N * F + f];
-        err_bits = err;
-        err_frames = (err != 0 || flag == 0) ? 1 : 0;
-        alarm = (err == 0 && flag == 0) ? 1 : 0;
-        fals = (err != 0 && flag == 1) ? 1 : 0;
-        its = itera;
+        const int err = errs[f], flag = flag_row[f];
+        errs[f] = 0; // leave the scratch zeroed for the next call
+        v[0] = (err != 0 || flag == 0) ? 1 : 0; // num_Error_Frames
+        v[1] = err;                              // num_Error_Bits
+        v[2] = itera;                            // Total_Iteration += iteraTime per frame (Simulation.cu:262)
+        v[3] = (err != 0 && flag == 1) ? 1 : 0; // num_False_Frames
+        v[4] = (err == 0 && flag == 0) ? 1 : 0; // num_Alarm_Frames
     }
-    // wave reduction, then one atomic per wave and counter
-    long long v[5] = {err_frames, err_bits, its, fals, alarm};
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         long long x = v[c];
