@@ -329,6 +329,240 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-row variant: each check row is shared by the two half-waves of one wave (lanes i and i+32 own the
+// two halves of the row's WC edges for the same t), each half-wave also owns its own set of variable
+// columns.  Twice the threads per frame at about half the registers each, i.e. twice the waves per SIMD for
+// the same LDS footprint -- on gfx950 one wave issues at most one VALU instruction per 4 cycles, a SIMD one
+// per 2, so the fused kernel needs >= 4-6 resident waves per SIMD to keep the VALU and the LDS pipe busy
+// through barriers.  The halves' (min1, min2, sign) meet through three v_permlane32_swap per frame.
+template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int GJ_, int MINW_> struct QcGeom2 {
+    static constexpr int NF = NF_, J = J_, L = L_, Z = Z_, WC = WC_, WV = WV_, GJ = GJ_, MINW = MINW_;
+    static constexpr int ZB = Z / 32, WCH = WC / 2, NCG = 2 * GJ;
+    static constexpr int RPT = J / GJ, CPT = L / NCG, TPB = GJ * ZB * 64;
+    static constexpr int MSG = NF * 4;
+    static constexpr int Sslot = J * WC * Z;
+    static constexpr int zero_slot = Sslot + L * Z;
+    static constexpr int inf_slot = zero_slot + 1;
+    static constexpr int flag_byte = (inf_slot + 1) * MSG;
+    static constexpr int lds_bytes = flag_byte + NF * 4;
+    static constexpr int NW = (L * Z) / 32;
+    static_assert(Z % 32 == 0 && WC % 2 == 0, "half-waves own 32 circulant positions and half a row each");
+    static_assert(J % GJ == 0 && L % NCG == 0, "groups must tile the block rows and columns");
+    static_assert(TPB <= 1024 && inf_slot < 65536, "geometry out of range");
+};
+
+__device__ __forceinline__ void swap32(float &lo_all, float &hi_all, float x)
+{
+    // lo_all <- x of lanes 0-31 in both halves, hi_all <- x of lanes 32-63 in both halves
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo_all = __uint_as_float(r[0]);
+    hi_all = __uint_as_float(r[1]);
+}
+
+template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc2(QcArgs a)
+{
+    constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, GJ = GM::GJ, ZB = GM::ZB, WCH = GM::WCH;
+    constexpr int RPT = GM::RPT, CPT = GM::CPT, NCG = GM::NCG, MSG = GM::MSG;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
+    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (wg >= a.nWG) return;
+
+    const int F = a.F;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, h = lane >> 5;
+    const int jq = wave / ZB, t = (wave - jq * ZB) * 32 + (lane & 31);
+    const int cg = jq * 2 + h;  // column group of this half-wave
+    const int f0 = wg * NF;
+    int *lds_flag = reinterpret_cast<int *>(lds + GM::flag_byte);
+
+    // row j = jq + rr*GJ, this thread's edges pp = h*WCH + i
+    const int rbase = ((jq * WC + h * WCH) * Z + t) * MSG;   // + (rr*GJ*WC + i)*Z*MSG
+    const int sbase = (GM::Sslot + cg * Z + t) * MSG;        // + cc*NCG*Z*MSG
+    unsigned saddr[RPT][(WCH + 1) / 2];
+    int e0v[RPT], wrv[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+        e0v[rr] = a.rowptr[jq + rr * GJ];
+        wrv[rr] = a.rowptr[jq + rr * GJ + 1] - e0v[rr];
+    }
+    int wcv[CPT];
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) wcv[cc] = a.wv[cg + cc * NCG];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+        QcCnEdge ed[WCH];
+#pragma unroll
+        for (int i = 0; i < WCH; i++) ed[i] = a.cn_edges[e0v[rr] + min(h * WCH + i, wrv[rr] - 1)];
+#pragma unroll
+        for (int i = 0; i < WCH; i++) {
+            int c = t + ed[i].shift;
+            c = (c >= Z) ? c - Z : c;
+            const int slot = (h * WCH + i < wrv[rr]) ? GM::Sslot + ed[i].col * Z + c : GM::inf_slot;
+            if (i & 1) saddr[rr][i / 2] |= (unsigned)slot << 16;
+            else saddr[rr][i / 2] = (unsigned)slot;
+            const float zero[NF] = {};
+            lds_st<NF>(lds, rbase + (rr * GJ * WC + i) * Z * MSG, zero);
+        }
+    }
+    float yreg[CPT][NF];
+    int raddr[CPT][WV];
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) {
+        const int l = cg + cc * NCG;
+        QcVnEdge ed[WV];
+#pragma unroll
+        for (int k = 0; k < WV; k++) ed[k] = a.vn_edges[l * WV + min(k, wcv[cc] - 1)];
+        {
+            typename Msg<NF>::T yv = *reinterpret_cast<const typename Msg<NF>::T *>(a.y + ((size_t)wg * (L * Z) + l * Z + t) * NF);
+            __builtin_memcpy(yreg[cc], &yv, sizeof(yv));
+        }
+#pragma unroll
+        for (int k = 0; k < WV; k++) {
+            int r = t - ed[k].shift;
+            r = (r < 0) ? r + Z : r;
+            raddr[cc][k] = ((k < wcv[cc]) ? ed[k].e * Z + r : GM::zero_slot) * MSG;
+        }
+    }
+    if (tid < NF) {
+        reinterpret_cast<float *>(lds)[GM::zero_slot * NF + tid] = 0.0f;
+        reinterpret_cast<float *>(lds)[GM::inf_slot * NF + tid] = __builtin_inff();
+        lds_flag[tid] = 0;
+    }
+    unsigned long long hist = 0;
+    __syncthreads();
+
+    auto vn_phase = [&](bool (&bad)[NF]) {
+        float R[CPT][WV][NF];
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++)
+#pragma unroll
+            for (int k = 0; k < WV; k++) lds_ld<NF>(R[cc][k], lds, raddr[cc][k]);
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            float S[NF];
+#pragma unroll
+            for (int v = 0; v < NF; v++) S[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < WV; k++) {
+#pragma unroll
+                for (int v = 0; v < NF; v++) S[v] += R[cc][k][v];
+            }
+#pragma unroll
+            for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
+            lds_st<NF>(lds, sbase + cc * NCG * Z * MSG, S);
+            if (HIST) {
+                const bool in_len = ((cg + cc * NCG) * Z + t) < a.length;
+#pragma unroll
+                for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
+            }
+        }
+    };
+    auto flags_publish = [&](const bool (&bad)[NF]) {
+#pragma unroll
+        for (int v = 0; v < NF; v++)
+            if (bad[v]) lds_flag[v] = 1;
+    };
+    auto flags_collect = [&](int it) -> int {
+        int flag = 0;
+        if (tid < NF) {
+            flag = lds_flag[tid] ? 0 : 1;
+            lds_flag[tid] = 0;
+            if (flag && it <= 64) hist |= (1ull << (it - 1));
+        }
+        return flag;
+    };
+
+    for (int it = 1; it < a.max_iter; it++) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+            for (int i = 0; i < (WCH + 1) / 2; i++) asm volatile("" : "+v"(saddr[rr][i]));
+        bool bad[NF];
+#pragma unroll
+        for (int v = 0; v < NF; v++) bad[v] = false;
+        vn_phase(bad);
+        if (HIST) flags_publish(bad);
+        __syncthreads();
+        if (HIST) (void)flags_collect(it);
+
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+            float Q[WCH][NF];
+            CnAcc acc[NF];
+#pragma unroll
+            for (int v = 0; v < NF; v++) acc[v].init();
+            {
+                float Sv[WCH][NF], Rv[WCH][NF];
+#pragma unroll
+                for (int i = 0; i < WCH; i++) {
+                    const unsigned pk = saddr[rr][i / 2];
+                    lds_ld<NF>(Sv[i], lds, (int)((i & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
+                    lds_ld<NF>(Rv[i], lds, rbase + (rr * GJ * WC + i) * Z * MSG);
+                }
+#pragma unroll
+                for (int i = 0; i < WCH; i++) {
+#pragma unroll
+                    for (int v = 0; v < NF; v++) {
+                        Q[i][v] = Sv[i][v] - Rv[i][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
+                        acc[v].add(Q[i][v]);
+                    }
+                }
+            }
+            // merge the two halves of the row: the two smallest of {m1,m2} U {m1',m2'}, XOR of the signs
+            uint32_t key[NF];
+            float m2[NF];
+#pragma unroll
+            for (int v = 0; v < NF; v++) {
+                float a1, b1, a2, b2, as, bs;
+                swap32(a1, b1, acc[v].m1);
+                swap32(a2, b2, acc[v].m2);
+                swap32(as, bs, __uint_as_float(acc[v].sgn));
+                const float m1 = __builtin_fminf(a1, b1);
+                m2[v] = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1, b1), a2), b2);
+                key[v] = (f2u(m1) ^ f2u(m2[v])) ^ ((f2u(as) ^ f2u(bs)) & 0x80000000u);
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; i++) {
+                float Rn[NF];
+#pragma unroll
+                for (int v = 0; v < NF; v++) Rn[v] = cn_out(Q[i][v], m2[v], key[v]);
+                lds_st<NF>(lds, rbase + (rr * GJ * WC + i) * Z * MSG, Rn);
+            }
+        }
+        __syncthreads();
+    }
+
+    {
+        bool bad[NF];
+#pragma unroll
+        for (int v = 0; v < NF; v++) bad[v] = false;
+        vn_phase(bad);
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            const int n = (cg + cc * NCG) * Z + t;
+            float S[NF];
+            lds_ld<NF>(S, lds, sbase + cc * NCG * Z * MSG);
+#pragma unroll
+            for (int v = 0; v < NF; v++) {
+                const bool neg = S[v] < 0;
+                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
+                const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave, see k_qc
+                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
+            }
+        }
+        flags_publish(bad);
+        __syncthreads();
+        const int flag = flags_collect(a.max_iter);
+        if (tid < NF && f0 + tid < F) {
+            a.D[(size_t)L * Z * F + f0 + tid] = flag;
+            if (HIST && a.hist) a.hist[f0 + tid] = hist;
+        }
+    }
+}
+
 // Regroup the reference's frame-fastest Channel_Out [N][F] into per-workgroup slabs [F/NF][N][NF] so that the
 // decode kernel's loads are contiguous along the circulant dimension (the reference layout would cost every
 // lane its own 128-byte line for 4*NF useful bytes).  64 x 64 tiles through LDS; reads and writes coalesced.
@@ -392,7 +626,7 @@ __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist
 
 // ---------------------------------------------------------------------------------------------
 using QcKernel = void (*)(QcArgs);
-struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; };
+struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; };
 
 // Ahead-of-time variants: one per block-matrix geometry of the reference's matrix set whose message
 // state fits one CU's LDS (shifts are run-time data, so every code of the same J x L x Z shape and
@@ -411,9 +645,19 @@ inline const QcVariant *qc_variants(int *count)
 #define X(NF, J, L, Z, WC, WV, G, MINW)                                                                  \
     {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW>::TPB,                              \
      QcGeom<NF, J, L, Z, WC, WV, G, MINW>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, false>,    \
-     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>},
-    static const QcVariant v[] = {QC_VARIANTS(X)};
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>, "row"},
+#define X2(NF, J, L, Z, WC, WV, GJ, MINW)                                                                 \
+    {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::TPB,                            \
+     QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, false>, \
+     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow"},
+    static const QcVariant v[] = {
+        X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
+        X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
+        X2(2, 12, 24, 96, 8, 6, 4, 3) /* J12_L24_Z96 (rows padded 7 -> 8): 768 thr, 92 KB                        */
+        X2(2, 6, 24, 96, 16, 4, 3, 3) /* J6_L24_Z96 (rows padded 15 -> 16): 576 thr, 92 KB                       */
+        QC_VARIANTS(X)};
 #undef X
+#undef X2
     *count = (int)(sizeof(v) / sizeof(v[0]));
     return v;
 }
@@ -497,8 +741,8 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
     q->frames_per_wg = v.NF;
-    snprintf(q->name, sizeof(q->name), "qc_lds<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.NF, v.J, v.L, v.Z, v.WC, v.WV, v.G,
-             v.MINW, v.threads, v.lds_bytes);
+    snprintf(q->name, sizeof(q->name), "qc_lds_%s<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.tag, v.NF, v.J, v.L, v.Z, v.WC, v.WV,
+             v.G, v.MINW, v.threads, v.lds_bytes);
     return BLDPC_OK;
 }
 
