@@ -76,6 +76,22 @@ def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
                       % (nframes, iters, dt)}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
+    written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command); None when
+    no summary exists for this kernel."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        if j.get("kernel") == kernel_name and j.get("hbm_bytes_per_launch"):
+            best = j["hbm_bytes_per_launch"]
+    return best
+
+
 def cpu_threads():
     """Host threads for the CPU baseline: this box's share for one GPU is 16 cores (gpurun contract)."""
     return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_CPU_THREADS", "16"))))
@@ -157,7 +173,8 @@ def run_nb(args, rank, world, dev, dist):
         "config": {"workload": "myNBLDPC BDS N576_K288 GF(64) EMS(Nm=2,Nc=2) batch=%d codewords/GPU Eb/N0=%.1fdB" % (frames, snr),
                    "kernel": "nb_ems<q64> one frame per workgroup", "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                     "traffic": pmc_traffic("nb_ems<q64> one frame per workgroup"), "kernel": "k_nb_ems<64>", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes},
         "stats": {"frames": n_all, "error_frames": c[0], "symbol_errors": c[1], "FER": c[0] / n_all, "SER": c[1] / n_all / code.N,
                   "mean_iterations": c[2] / n_all},
     }
@@ -232,6 +249,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    code.set_profiling(True)
     for _ in range(args.warmup):
         step()
     SIM._dev.zero_()
@@ -244,6 +262,8 @@ def main():
         ev[k][1].record(stream)
         check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, frames, 0, r["iteraTime"],
                                   ctypes.c_void_p(SIM._dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream)), "Statistic")
+        if k == args.steps - 1:
+            dom_ms_last = code.last_kernel_ms()  # dominant kernel alone (events recorded inside bldpc_decode)
     counters = SIM._dev.clone()
     if world > 1:
         dist.all_reduce(counters)  # the only collective: 5 int64 error counters
@@ -253,7 +273,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    call_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # whole bldpc_decode call (regroup + decode + unpack)
+    kern_ms = dom_ms_last
 
     if rank == 0:
         total_cw = frames * world * args.steps
@@ -268,7 +289,8 @@ def main():
             "config": {"workload": "%s rate-%.3f batch=%d codewords/GPU %d iters Es/N0=%.1fdB" % (args.workload, code.K / N, frames, iters, snr),
                        "kernel": code.last_kernel, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": pmc_traffic(code.last_kernel), "kernel": code.last_kernel, "kernel_ms": kern_ms, "decode_call_ms": call_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
             "stats": {"frames": frames * world * args.steps, "error_frames": c[0], "error_bits": c[1],
                       "FER": c[0] / (frames * world * args.steps), "BER": c[1] / (frames * world * args.steps) / code.K},
         }

@@ -102,6 +102,15 @@ class BinaryCode:
     def last_kernel(self):
         return lib.bldpc_last_kernel(self._h).decode()
 
+    def set_profiling(self, enable=True):
+        check(lib.bldpc_set_profiling(self._h, 1 if enable else 0), "bldpc_set_profiling")
+
+    def last_kernel_ms(self):
+        """Elapsed ms of the dominant kernel of the last LDPC_Decoder_GPU call (HIP events on its stream)."""
+        ms = ctypes.c_float(0)
+        check(lib.bldpc_last_kernel_ms(self._h, ctypes.byref(ms)), "bldpc_last_kernel_ms")
+        return ms.value
+
     def close(self):
         if self._h:
             lib.bldpc_code_destroy(self._h)

@@ -29,6 +29,8 @@ struct bldpc_code {
     int *h_cnt = nullptr; // pinned
     QcPlan qc;            // fused LDS kernel description (frames_per_wg == 0: unavailable)
     const char *last_kernel = "none";
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 extern "C" const char *bldpc_last_error(void) { return err_buf(); }
@@ -207,6 +209,8 @@ extern "C" int bldpc_code_destroy(bldpc_code *c)
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     c->rq.release(); c->bad.release(); c->cnt.release(); c->bits.release(); c->yg.release(); c->errs.release();
     qc_plan_release(&c->qc);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
     return BLDPC_OK;
 }
@@ -220,6 +224,25 @@ extern "C" int bldpc_code_dims(const bldpc_code *c, int dims[8])
 }
 
 extern "C" const char *bldpc_last_kernel(const bldpc_code *c) { return c ? c->last_kernel : "none"; }
+
+extern "C" int bldpc_set_profiling(bldpc_code *c, int enable)
+{
+    if (!c) return fail(BLDPC_EINVAL, "bldpc_set_profiling: null code");
+    if (enable && !c->ev0) {
+        CLDPC_HIP(hipEventCreate(&c->ev0), BLDPC_EHIP);
+        CLDPC_HIP(hipEventCreate(&c->ev1), BLDPC_EHIP);
+    }
+    c->profiling = enable != 0;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_last_kernel_ms(bldpc_code *c, float *ms)
+{
+    if (!c || !ms || !c->ev0) return fail(BLDPC_EINVAL, "bldpc_last_kernel_ms: profiling was not enabled");
+    CLDPC_HIP(hipEventSynchronize(c->ev1), BLDPC_EHIP);
+    CLDPC_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1), BLDPC_EHIP);
+    return BLDPC_OK;
+}
 
 // ---------------------------------------------------------------------------
 template <int VEC>
@@ -289,7 +312,8 @@ extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, 
         CLDPC_HIP(c->bits.reserve((size_t)F * (c->N / 32) * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(c->yg.reserve(((size_t)F + 2) * c->N * sizeof(float)), BLDPC_ENOMEM);
         int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
-                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, st);
+                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, st,
+                          c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr);
         c->last_kernel = c->qc.name;
         return r;
     }
@@ -298,12 +322,17 @@ extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, 
     CLDPC_HIP(c->bad.reserve((size_t)F * sizeof(unsigned long long)), BLDPC_ENOMEM);
     CLDPC_HIP(c->cnt.reserve(64), BLDPC_ENOMEM);
     const bool a16 = ((uintptr_t)y % 16 == 0) && ((uintptr_t)D % 16 == 0) && (!app || (uintptr_t)app % 16 == 0);
+    if (c->profiling) CLDPC_HIP(hipEventRecord(c->ev0, st), BLDPC_EHIP);
+    int r;
     if (F % 4 == 0 && a16) {
         c->last_kernel = "table_vec4";
-        return run_table<4>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+        r = run_table<4>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+    } else {
+        c->last_kernel = "table_vec1";
+        r = run_table<1>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
     }
-    c->last_kernel = "table_vec1";
-    return run_table<1>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+    if (c->profiling) CLDPC_HIP(hipEventRecord(c->ev1, st), BLDPC_EHIP);
+    return r;
 }
 
 extern "C" int bldpc_statistic(const bldpc_code *cc, const int *D, const int *cw, int F, int length, int itera, long long *counters,

@@ -760,7 +760,7 @@ inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStre
 
 // y here is the regrouped buffer produced by qc_regroup.
 inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
-                     unsigned long long *hist, unsigned *bits, hipStream_t st)
+                     unsigned long long *hist, unsigned *bits, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
@@ -771,7 +771,9 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
     a.max_iter = max_iter; a.length = length;
     const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
+    if (ev0) (void)hipEventRecord(ev0, st);
     hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), v.lds_bytes, st, a);
+    if (ev1) (void)hipEventRecord(ev1, st);
     const int NW = v.L * v.Z / 32;
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
@@ -782,7 +784,7 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 // yg: device float [ceil(F/NF)*NF][N] workspace for the regrouped channel values.
 inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
                      unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, unsigned *bits,
-                     float *yg, int *itera, hipStream_t st)
+                     float *yg, int *itera, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     {
         int rr = qc_regroup(q, y, yg, F, st);
@@ -791,14 +793,14 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     }
     if (exit_mode == BLDPC_EXIT_FIXED) {
         *itera = max_iter;
-        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, bits, st);
+        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, bits, st, ev0, ev1);
     }
     // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are
     // flagged.  Pass 1 runs max_iter iterations on-chip recording each frame's flag history; the AND of
     // the histories gives that iteration; if it is earlier than max_iter, pass 2 replays exactly that many.
     if (max_iter > 64) return fail(BLDPC_EUNSUPPORTED, "QC_LDS with BATCH_GLOBAL exit supports max_iter <= 64 (got %d)", max_iter);
     unsigned long long *hist = flag_hist ? flag_hist : hist_ws;
-    int r = qc_launch(q, y, F, max_iter, length, D, app, hist, bits, st);
+    int r = qc_launch(q, y, F, max_iter, length, D, app, hist, bits, st, ev0, ev1);
     if (r) return r;
     const unsigned long long ones = ~0ull;
     CLDPC_HIP(hipMemcpyAsync(and_ws, &ones, sizeof(ones), hipMemcpyHostToDevice, st), BLDPC_EHIP);

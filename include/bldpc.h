@@ -124,6 +124,13 @@ int bldpc_awgn_channel_host(int seed[3], float sigma, float *Channel_Out, const 
 /* sigma of the sweep point (main.cu:120-127): snrtype 0 = Eb/N0 (uses rate), 1 = Es/N0. */
 float bldpc_sigma(float SNR, int snrtype, float rate);
 
+/* Timing of the dominant kernel (k_qc / k_qc2, or the VN+CN launch sequence of the table kernels) with
+ * HIP events on the stream the kernel runs on.  enable != 0 makes every following bldpc_decode record a
+ * pair of events around that kernel; bldpc_last_kernel_ms waits for the last pair and returns the
+ * elapsed milliseconds in *ms.  Used by bench.py for the roofline line; off by default. */
+int bldpc_set_profiling(bldpc_code *code, int enable);
+int bldpc_last_kernel_ms(bldpc_code *code, float *ms);
+
 /* Name of the kernel variant the last bldpc_decode on this code used (static string). */
 const char *bldpc_last_kernel(const bldpc_code *code);
 
