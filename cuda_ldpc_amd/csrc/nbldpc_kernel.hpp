@@ -21,7 +21,7 @@
 
 namespace cldpc {
 
-constexpr int kNbThreads = 512;
+constexpr int kNbThreads = 1024;
 constexpr int kNbMaxDv = 8;
 constexpr int kNbMaxW = 6; // row weights handled by the templated walk
 
@@ -200,14 +200,15 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = kNbThreads / 64;
     const int N = a.N, M = a.M, q = a.q, dv = a.dv, dc = a.dc;
     const int NE = N * dv, TC = M * dc, PST = nb_pair_stride(q);
+    const int TCP = TC + 1; // E row stride: odd, so a variable node reading one thread's column across symbols spreads over the banks
     float *pairs = lds;                    // [NE][PST]
     float *E = pairs + NE * PST;           // [q][TC]
-    int *outs = reinterpret_cast<int *>(E + q * TC);  // [N]
+    int *outs = reinterpret_cast<int *>(E + q * TCP);  // [N]
     int *flag = outs + N;                  // [4]
     unsigned char *mulb = reinterpret_cast<unsigned char *>(flag + 4); // [q][q]
 
     for (int i = tid; i < q * q; i += kNbThreads) mulb[i] = a.mul[i];
-    for (int i = tid; i < q * TC; i += kNbThreads) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+    for (int i = tid; i < q * TCP; i += kNbThreads) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
     if (tid == 0) flag[0] = 0;
     __syncthreads();
 
@@ -229,7 +230,7 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
                 if (d < w) {
                     const int thr = a.vn_thr[col * dv + d], h = a.vn_gf[col * dv + d];
                     const float e0 = E[thr];
-                    const float ev = E[mulb[sym * q + h] * TC + thr];
+                    const float ev = E[mulb[sym * q + h] * TCP + thr];
                     c2[d] = (float)((double)(ev - e0) / 1.2); // :309, double division
                     llr = llr + c2[d];                         // :208-213, ascending d
                 }
@@ -269,7 +270,7 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
             const uint32_t ua = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
             const unsigned long long keyk = ((unsigned long long)ua << 32) | (unsigned)(63 - lane);
             int rank = 0; // # elements that precede this one = # greater + # equal with a smaller index
-#pragma unroll
+#pragma unroll 8
             for (int j = 0; j < Q; j++) {
                 const uint32_t hj = __builtin_amdgcn_readlane(ua, j);
                 const unsigned long long keyj = ((unsigned long long)hj << 32) | (unsigned)(63 - j);
@@ -288,11 +289,11 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
             const int row = tid / dc, e = tid - row * dc, w = a.cn_w[row];
             if (e < w) {
                 switch (w) {
-                case 2: nb_cn_update<2, Q>(a, pairs, E, TC, row, e, tid); break;
-                case 3: nb_cn_update<3, Q>(a, pairs, E, TC, row, e, tid); break;
-                case 4: nb_cn_update<4, Q>(a, pairs, E, TC, row, e, tid); break;
-                case 5: nb_cn_update<5, Q>(a, pairs, E, TC, row, e, tid); break;
-                case 6: nb_cn_update<6, Q>(a, pairs, E, TC, row, e, tid); break;
+                case 2: nb_cn_update<2, Q>(a, pairs, E, TCP, row, e, tid); break;
+                case 3: nb_cn_update<3, Q>(a, pairs, E, TCP, row, e, tid); break;
+                case 4: nb_cn_update<4, Q>(a, pairs, E, TCP, row, e, tid); break;
+                case 5: nb_cn_update<5, Q>(a, pairs, E, TCP, row, e, tid); break;
+                case 6: nb_cn_update<6, Q>(a, pairs, E, TCP, row, e, tid); break;
                 default: break;
                 }
             }
@@ -312,7 +313,7 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
         if (e < a.cn_w[row]) {
             const int h = a.cn_gf[tid];
             const float e0 = E[tid];
-            for (int k = 1; k < q; k++) o[k - 1] = (float)((double)(E[mulb[k * q + h] * TC + tid] - e0) / 1.2);
+            for (int k = 1; k < q; k++) o[k - 1] = (float)((double)(E[mulb[k * q + h] * TCP + tid] - e0) / 1.2);
         } else {
             for (int k = 1; k < q; k++) o[k - 1] = 0.0f;
         }
