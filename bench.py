@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--workload", default="J4_L24_Z96", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "qc", "table"])
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU")
+    ap.add_argument("--snr", type=float, default=None, help="override the SNR point (experiments only)")
     ap.add_argument("--iters", type=int, default=0, help="override the iteration count (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the cpu_baseline sample (0 = auto)")
@@ -118,6 +119,8 @@ def run_nb(args, rank, world, dev, dist):
     name, _, _, _, frames, snr, iters = WORKLOADS[args.workload]
     if args.frames:
         frames = args.frames
+    if args.snr is not None:
+        snr = args.snr
     nbd = os.path.join(ROOT, "data", "nb")
     mul, _, _ = nb.GFInitial(64, os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
     code = nb.NBCode(os.path.join(nbd, name), mul)

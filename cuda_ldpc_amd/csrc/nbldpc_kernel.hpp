@@ -13,11 +13,16 @@
 //   A  one wave per variable node, lane k <-> vector element k: c2v from E (the double division of
 //      :309), LLR = L_ch + sum c2v (:202-214), hard decision (:71-91), v2c = LLR - c2v (:241-251)
 //   S  syndrome over GF(q) (:218-238); a frame leaves as soon as it is zero
-//   B  one wave per edge: stable descending sort (:17-36,253-269) by rank = #greater + #equal-before
+//   B  one wave per edge: stable descending sort (:17-36,253-269) as a 64-lane bitonic network over the
+//      pairwise-distinct keys (order-preserving image of the value, 63 - index)
 //   C  one thread per (row, edge): conf(q,1) then conf(Nm,Nc) (:272-303, :319-359) into E
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifndef NB_ABLATE
+#define NB_ABLATE 0 // experiments only (timing, wrong results): 1 no CN phase, 2 no rank loop, 4 no double division, 8 no VN phase A math
+#endif
 
 namespace cldpc {
 
@@ -50,6 +55,49 @@ __device__ __forceinline__ float nb_wave_max(float v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
+}
+
+
+// 64-lane bitonic sort, descending, of the pairwise-distinct 64-bit keys (hi, lo).  One compare-exchange step:
+// the partner lane's key arrives through the LDS crossbar (ds_swizzle / ds_bpermute, no VALU), the compare is
+// a 64-bit subtract-with-borrow chain on VCC, the keep-max lane pattern of the step is a compile-time constant
+// XNORed into VCC on the scalar unit.
+__host__ __device__ constexpr unsigned long long nb_keepmax_mask(int K, int J)
+{
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) {
+        const bool lower = (i & J) == 0, up = (K >= 64) ? true : ((i & K) == 0);
+        if (lower == up) m |= 1ull << i;
+    }
+    return m;
+}
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_step(uint32_t &hi, uint32_t &lo)
+{
+    uint32_t phi, plo, t;
+    if constexpr (J < 32) {
+        phi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)hi, (J << 10) | 0x1f);
+        plo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)lo, (J << 10) | 0x1f);
+    } else {
+        phi = (uint32_t)__shfl_xor((int)hi, 32, 64);
+        plo = (uint32_t)__shfl_xor((int)lo, 32, 64);
+    }
+    constexpr unsigned long long KM = nb_keepmax_mask(K, J);
+    // vcc = (partner > mine); take the partner's key where that equals "this lane keeps the larger one"
+    asm volatile("v_sub_co_u32 %2, vcc, %1, %4\n\tv_subb_co_u32 %2, vcc, %0, %3, vcc\n\ts_xnor_b64 vcc, vcc, %5\n\t"
+                 "v_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc"
+                 : "+v"(hi), "+v"(lo), "=&v"(t)
+                 : "v"(phi), "v"(plo), "s"(KM)
+                 : "vcc");
+}
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_merge(uint32_t &hi, uint32_t &lo)
+{
+    nb_bitonic_step<K, J>(hi, lo);
+    if constexpr (J > 1) nb_bitonic_merge<K, J / 2>(hi, lo);
+}
+template <int K> __device__ __forceinline__ void nb_bitonic_sort(uint32_t &hi, uint32_t &lo)
+{
+    if constexpr (K > 2) nb_bitonic_sort<K / 2>(hi, lo);
+    nb_bitonic_merge<K, K / 2>(hi, lo);
 }
 
 template <int NACT> struct NbCn {
@@ -167,7 +215,7 @@ template <int D, int NACT> __device__ void nb_conf(NbCn<NACT> &c, int symbase, i
 }
 
 template <int W, int Q>
-__device__ void nb_cn_update(const NbArgs &a, const float *pairs, float *E, int TC, int row, int e, int thr)
+__device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, const float *pairs, float *E, int TC, int row, int e, int thr)
 {
     constexpr int NACT = W - 1;
     NbCn<NACT> c;
@@ -178,7 +226,7 @@ __device__ void nb_cn_update(const NbArgs &a, const float *pairs, float *E, int 
 #pragma unroll
     for (int i = 0; i < NACT; i++) {
         const int pos = i + (i >= e ? 1 : 0); // ascending positions, skipping `except` (:327-331)
-        c.pb[i] = a.cn_src[row * a.dc + pos] * PST;
+        c.pb[i] = cn_src[row * a.dc + pos] * PST;
         const float2 p0 = *reinterpret_cast<const float2 *>(pairs + c.pb[i]);
         const float2 p1 = *reinterpret_cast<const float2 *>(pairs + c.pb[i] + 2);
         c.v0[i] = p0.x; c.m0[i] = __float_as_int(p0.y);
@@ -206,6 +254,21 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
     int *outs = reinterpret_cast<int *>(E + q * TCP);  // [N]
     int *flag = outs + N;                  // [4]
     unsigned char *mulb = reinterpret_cast<unsigned char *>(flag + 4); // [q][q]
+    // graph tables as u16 in LDS: a global load whose value steers a branch or an address costs ~1 us each,
+    // and the phases below would pay it per node / per edge / per iteration
+    unsigned short *t_vn_w = reinterpret_cast<unsigned short *>(mulb + q * q); // [N]
+    unsigned short *t_vn_thr = t_vn_w + N;      // [N][dv]
+    unsigned short *t_vn_gf = t_vn_thr + NE;    // [N][dv]
+    unsigned short *t_cn_w = t_vn_gf + NE;      // [M]
+    unsigned short *t_cn_src = t_cn_w + M;      // [M][dc]
+    unsigned short *t_cn_gf = t_cn_src + TC;    // [M][dc]
+    unsigned short *t_cn_vn = t_cn_gf + TC;     // [M][dc]
+    for (int i = tid; i < N; i += kNbThreads) t_vn_w[i] = (unsigned short)a.vn_w[i];
+    for (int i = tid; i < NE; i += kNbThreads) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
+    for (int i = tid; i < M; i += kNbThreads) t_cn_w[i] = (unsigned short)a.cn_w[i];
+    for (int i = tid; i < TC; i += kNbThreads) {
+        t_cn_src[i] = (unsigned short)a.cn_src[i]; t_cn_gf[i] = (unsigned short)a.cn_gf[i]; t_cn_vn[i] = (unsigned short)a.cn_vn[i];
+    }
 
     for (int i = tid; i < q * q; i += kNbThreads) mulb[i] = a.mul[i];
     for (int i = tid; i < q * TCP; i += kNbThreads) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
@@ -221,17 +284,18 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
         it++;
         // ---- A: variable nodes ------------------------------------------------------------
         for (int col = wave; col < N; col += nwaves) {
-            const int w = a.vn_w[col];
+            const int w = t_vn_w[col];
             float llr = active ? Lch[col * (q - 1) + lane] : 0.0f;
             float c2[kNbMaxDv];
 #pragma unroll
             for (int d = 0; d < kNbMaxDv; d++) {
                 c2[d] = 0.0f;
                 if (d < w) {
-                    const int thr = a.vn_thr[col * dv + d], h = a.vn_gf[col * dv + d];
+                    const int thr = t_vn_thr[col * dv + d], h = t_vn_gf[col * dv + d];
                     const float e0 = E[thr];
                     const float ev = E[mulb[sym * q + h] * TCP + thr];
-                    c2[d] = (float)((double)(ev - e0) / 1.2); // :309, double division
+                    if (!(NB_ABLATE & 4)) c2[d] = (float)((double)(ev - e0) / 1.2); // :309, double division
+                    else c2[d] = (ev - e0) * 0.83f;
                     llr = llr + c2[d];                         // :208-213, ascending d
                 }
             }
@@ -250,7 +314,7 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
         // ---- S: syndrome (:218-238) ----------------------------------------------------------
         if (tid < M) {
             int s = 0;
-            for (int i = 0; i < a.cn_w[tid]; i++) s ^= mulb[outs[a.cn_vn[tid * dc + i]] * q + a.cn_gf[tid * dc + i]];
+            for (int i = 0; i < t_cn_w[tid]; i++) s ^= mulb[outs[t_cn_vn[tid * dc + i]] * q + t_cn_gf[tid * dc + i]];
             if (s) flag[0] = 1;
         }
         __syncthreads();
@@ -262,38 +326,35 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
         // ---- B: stable descending sort of every v2c vector (:17-36, :253-269) -----------------
         for (int edge = wave; edge < NE; edge += nwaves) {
             const int col = edge / dv, d = edge - col * dv;
-            if (d >= a.vn_w[col]) continue;
-            const int h = a.vn_gf[edge];
+            if (d >= t_vn_w[col]) continue;
+            const int h = t_vn_gf[edge];
             const float val = (lane < q) ? pairs[edge * PST + 2 * lane] : 0.0f;
             // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
             const uint32_t b = __float_as_uint(val + 0.0f);
             const uint32_t ua = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
-            const unsigned long long keyk = ((unsigned long long)ua << 32) | (unsigned)(63 - lane);
-            int rank = 0; // # elements that precede this one = # greater + # equal with a smaller index
-#pragma unroll 8
-            for (int j = 0; j < Q; j++) {
-                const uint32_t hj = __builtin_amdgcn_readlane(ua, j);
-                const unsigned long long keyj = ((unsigned long long)hj << 32) | (unsigned)(63 - j);
-                rank += (keyj > keyk) ? 1 : 0;
-            }
+            // stable descending order = descending order of the distinct keys (value image, 63 - index)
+            uint32_t khi = ua, klo = 63u - (unsigned)lane;
+            if (!(NB_ABLATE & 2)) nb_bitonic_sort<64>(khi, klo);
+            const int idx = 63 - (int)klo; // original position of the element that belongs at position `lane`
             if (lane < q) {
+                const int symk = (idx < q - 1) ? idx + 1 : 0;
                 float2 pr;
-                pr.x = val;
-                pr.y = __int_as_float((int)mulb[sym * q + h]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
-                *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * rank) = pr;
+                pr.x = pairs[edge * PST + 2 * idx];
+                pr.y = __int_as_float((int)mulb[symk * q + h]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
+                *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * lane) = pr;
             }
         }
         __syncthreads();
         // ---- C: check nodes (:272-303) -----------------------------------------------------------
         if (tid < TC) {
-            const int row = tid / dc, e = tid - row * dc, w = a.cn_w[row];
-            if (e < w) {
+            const int row = tid / dc, e = tid - row * dc, w = t_cn_w[row];
+            if (e < w && !(NB_ABLATE & 1)) {
                 switch (w) {
-                case 2: nb_cn_update<2, Q>(a, pairs, E, TCP, row, e, tid); break;
-                case 3: nb_cn_update<3, Q>(a, pairs, E, TCP, row, e, tid); break;
-                case 4: nb_cn_update<4, Q>(a, pairs, E, TCP, row, e, tid); break;
-                case 5: nb_cn_update<5, Q>(a, pairs, E, TCP, row, e, tid); break;
-                case 6: nb_cn_update<6, Q>(a, pairs, E, TCP, row, e, tid); break;
+                case 2: nb_cn_update<2, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
+                case 3: nb_cn_update<3, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
+                case 4: nb_cn_update<4, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
+                case 5: nb_cn_update<5, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
+                case 6: nb_cn_update<6, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
                 default: break;
                 }
             }
@@ -310,8 +371,8 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
     if (a.c2v && tid < TC) {
         const int row = tid / dc, e = tid - row * dc;
         float *o = a.c2v + ((size_t)frame * TC + tid) * (q - 1);
-        if (e < a.cn_w[row]) {
-            const int h = a.cn_gf[tid];
+        if (e < t_cn_w[row]) {
+            const int h = t_cn_gf[tid];
             const float e0 = E[tid];
             for (int k = 1; k < q; k++) o[k - 1] = (float)((double)(E[mulb[k * q + h] * TCP + tid] - e0) / 1.2);
         } else {
