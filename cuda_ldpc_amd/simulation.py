@@ -50,7 +50,8 @@ def Simulation_GPU(code, seed, sigma, SIM, Num_Frames_OneTime=4096, maxIT=50, ex
         SIM.num_Alarm_Frames += c[4]
         batches += 1
         stop = SIM.num_Error_Frames >= leastErrorFrames and SIM.num_Frames >= leastTestFrames
-        if rank == 0 and log and (SIM.num_Frames % displayStep == 0 or stop):
+        last = max_batches is not None and batches >= max_batches
+        if rank == 0 and log and (SIM.num_Frames % displayStep == 0 or stop or last):
             log(format_row(SIM, length))
         if stop or (max_batches is not None and batches >= max_batches):
             return 1 if stop else 0

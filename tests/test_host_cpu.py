@@ -139,3 +139,18 @@ def test_nb_matrix_reader(nbm, orc):
     for a, b in zip(arrs, (oc.vn_w, oc.vn_cn, oc.vn_gf, oc.cn_w, oc.cn_vn, oc.cn_gf)):
         assert np.array_equal(a, b)
     assert lib.nbldpc_read_matrix(b"/nonexistent", dims.ctypes.data_as(ctypes.c_void_p), None, None, None, None, None, None) != 0
+
+
+def test_c_program_links_against_the_abi(C, orc, tmp_path):
+    """A plain C translation unit includes include/*.h, links libcuda_ldpc_amd.so and runs the host-side entry points."""
+    import subprocess
+    from cuda_ldpc_amd._lib import SO_PATH
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+                           "-o", exe, "-L", libdir, "-lcuda_ldpc_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([exe, os.path.join(BL, "J4_L24_Z96_BlockH.txt")]).decode()
+    oc = orc.BinaryCode(os.path.join(BL, "J4_L24_Z96_BlockH.txt"), 4, 24, 96)
+    assert "Wc=20 Wv=4" in out and ("addrsum=%d" % int(oc.addr.astype(np.int64).sum())) in out
+    assert "y0=0.865149975" in out            # SURVEY Appendix D.3 anchor (Es/N0 3 dB)
+    assert "mul[2][33]=" in out and "can not open file" in out
