@@ -57,6 +57,18 @@ def AWGNChannel_CPU(seed, sigma, N, F, CodeWord=None):
     return out
 
 
+def AWGNChannel_GPU(seed, sigma, N, F, device=None, CodeWord=None, stream=None):
+    """The same channel generated on the device (bldpc_awgn_channel_device): identical RandomModule draws via LCG
+    jump-ahead, device libm for the Box-Muller transform.  Returns a CUDA float32 tensor [N, F]; seed advanced."""
+    if not (isinstance(seed, np.ndarray) and seed.dtype == np.int32 and seed.size == 3):
+        raise ValueError("seed must be an int32 numpy array of 3")
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((N, F), dtype=torch.float32, device=device)
+    st = ctypes.c_void_p((stream or torch.cuda.current_stream(device)).cuda_stream)
+    check(lib.bldpc_awgn_channel_device(_np_ptr(seed), ctypes.c_float(sigma), _dev_ptr(out), _dev_ptr(CodeWord), N, F, st), "AWGNChannel_GPU")
+    return out
+
+
 def sigma_of(SNR, snrtype=1, rate=0.0):
     """sigma of a sweep point (main.cu:120-127); snrtype 1 = Es/N0 (the reference default, define.cuh:45)."""
     return float(lib.bldpc_sigma(np.float32(SNR), snrtype, np.float32(rate)))

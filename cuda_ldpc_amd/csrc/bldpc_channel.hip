@@ -36,6 +36,63 @@ extern "C" int bldpc_awgn_channel_host(int seed[3], float sigma, float *out, con
     return BLDPC_OK;
 }
 
+namespace {
+constexpr unsigned kA[3] = {249u, 251u, 252u}, kM[3] = {61967u, 63443u, 63599u}; // LDPC_Encoder.cu:48-50
+
+__host__ __device__ inline unsigned powmod(unsigned a, unsigned long long k, unsigned m)
+{
+    unsigned long long r = 1, b = a % m;
+    while (k) {
+        if (k & 1) r = (r * b) % m;
+        b = (b * b) % m;
+        k >>= 1;
+    }
+    return (unsigned)r;
+}
+
+// One thread per (frame f, run of kRun consecutive bits): jump the three LCGs to the first draw of the run
+// (draw index 2*(f*N + n0)), then step them as RandomModule does.  threadIdx.x runs along f: stores coalesce.
+constexpr int kRun = 32;
+__global__ __launch_bounds__(256) void k_awgn(unsigned s0, unsigned s1, unsigned s2, float sigma, float *out, const int *cw, int N, int F)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * kRun;
+    if (f >= F) return;
+    const unsigned long long k = 2ull * ((unsigned long long)f * N + n0);
+    unsigned s[3] = {s0, s1, s2};
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i] = (unsigned)(((unsigned long long)s[i] * powmod(kA[i], k, kM[i])) % kM[i]);
+    const double two_pi = 2 * 3.1415926;
+    for (int n = n0; n < min(N, n0 + kRun); n++) {
+        float u[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) s[i] = (s[i] * kA[i]) % kM[i];
+            float t = ((float)(int)s[0] / 61967.0f) + ((float)(int)s[1] / 63443.0f) + ((float)(int)s[2] / 63599.0f);
+            t -= (int)t;
+            u[d] = t;
+        }
+        const float amp = sqrtf(-2.0f * logf(1.0f - u[0]));
+        const int c = cw ? cw[(size_t)n * F + f] : 0;
+        out[(size_t)n * F + f] = (float)((double)sigma * sin(two_pi * (double)u[1]) * (double)amp + 1.0 - (double)(2 * c));
+    }
+}
+} // namespace
+
+extern "C" int bldpc_awgn_channel_device(int seed[3], float sigma, float *out, const int *cw, int N, int F, void *stream)
+{
+    if (!seed || !out || N <= 0 || F <= 0) return cldpc::fail(BLDPC_EINVAL, "bldpc_awgn_channel_device: bad argument");
+    for (int i = 0; i < 3; i++)
+        if (seed[i] < 0 || (unsigned)seed[i] >= kM[i]) return cldpc::fail(BLDPC_EINVAL, "seed[%d]=%d outside [0,%u)", i, seed[i], kM[i]);
+    hipLaunchKernelGGL(k_awgn, dim3((unsigned)((F + 255) / 256), (unsigned)((N + kRun - 1) / kRun)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned)seed[0], (unsigned)seed[1], (unsigned)seed[2], sigma, out, cw, N, F);
+    CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
+    const unsigned long long draws = 2ull * (unsigned long long)N * F;
+    for (int i = 0; i < 3; i++) seed[i] = (int)(((unsigned long long)seed[i] * powmod(kA[i], draws, kM[i])) % kM[i]);
+    return BLDPC_OK;
+}
+
 extern "C" float bldpc_sigma(float snr, int snrtype, float rate)
 {
     if (snrtype == 0) return (float)std::sqrt(0.5 / (rate * std::pow(10.0, (double)(snr / 10.0))));

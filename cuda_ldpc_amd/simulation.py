@@ -10,14 +10,14 @@ import numpy as np
 import torch
 
 from . import sharding
-from .bldpc import (EXIT_BATCH_GLOBAL, KERNEL_AUTO, AWGNChannel_CPU, LDPC_Decoder_GPU, SimCounters, sigma_of)
+from .bldpc import (EXIT_BATCH_GLOBAL, KERNEL_AUTO, AWGNChannel_CPU, AWGNChannel_GPU, LDPC_Decoder_GPU, SimCounters, sigma_of)
 from ._lib import check, lib
 import ctypes
 
 
 def Simulation_GPU(code, seed, sigma, SIM, Num_Frames_OneTime=4096, maxIT=50, exit_mode=EXIT_BATCH_GLOBAL, kernel=KERNEL_AUTO,
                    leastErrorFrames=50, leastTestFrames=10000, displayStep=40960, dist=None, device=None, max_batches=None,
-                   log=print):
+                   log=print, device_channel=False):
     """One SNR point (Simulation.cu:12-171).  `seed` (int32[3]) is the AWGN->seed state, advanced in place by the
     WHOLE batch on every rank so that all ranks stay on the reference's single noise stream."""
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
@@ -33,11 +33,16 @@ def Simulation_GPU(code, seed, sigma, SIM, Num_Frames_OneTime=4096, maxIT=50, ex
     while True:
         SIM.num_Frames += F  # Simulation.cu:113
         my_seed = sharding.lcg_jump(seed, first * per_frame)
-        y = AWGNChannel_CPU(my_seed, sigma, code.N, count) if count else None
+        if not count:
+            yd = None
+        elif device_channel:  # same draws, generated on the GPU (device libm in the Box-Muller transform)
+            yd = AWGNChannel_GPU(my_seed, sigma, code.N, count, device=device)
+        else:
+            yd = torch.from_numpy(AWGNChannel_CPU(my_seed, sigma, code.N, count)).to(device)
         seed[:] = sharding.lcg_jump(seed, F * per_frame)
         dev_cnt.zero_()
         if count:
-            r = LDPC_Decoder_GPU(code, torch.from_numpy(y).to(device), max_iter=maxIT, length=length, exit_mode=exit_mode, kernel=kernel, D=D)
+            r = LDPC_Decoder_GPU(code, yd, max_iter=maxIT, length=length, exit_mode=exit_mode, kernel=kernel, D=D)
             st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, count, length, r["iteraTime"],
                                       ctypes.c_void_p(dev_cnt.data_ptr()), st), "Statistic")

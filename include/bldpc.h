@@ -121,6 +121,15 @@ int bldpc_statistic(const bldpc_code *code, const int *D, const int *CodeWord, i
  * NULL for the all-zero codeword. */
 int bldpc_awgn_channel_host(int seed[3], float sigma, float *Channel_Out, const int *CodeWord, int N, int F);
 
+/* Device-side input generator: the same channel on the GPU.  The three LCGs of RandomModule are
+ * advanced by modular exponentiation (seed * a^k mod m), so thread (f, n) produces exactly the draws u1, u2 the
+ * serial host loop would have produced for that sample (integer and IEEE float arithmetic only: bit-identical);
+ * the Box-Muller transform then uses the device math library, whose logf / sin differ from glibc's in the last
+ * ulp on a small fraction of arguments -- samples are identical or 1 ulp apart, statistically the same channel.
+ * Channel_Out: DEVICE float [N][F]; CodeWord: device int32 [N][F] or NULL.  seed[3] (host) is advanced by the
+ * whole batch exactly like bldpc_awgn_channel_host. */
+int bldpc_awgn_channel_device(int seed[3], float sigma, float *Channel_Out, const int *CodeWord, int N, int F, void *stream);
+
 /* sigma of the sweep point (main.cu:120-127): snrtype 0 = Eb/N0 (uses rate), 1 = Es/N0. */
 float bldpc_sigma(float SNR, int snrtype, float rate);
 

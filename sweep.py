@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--max-batches", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--fixed", action="store_true", help="fixed iteration count instead of the reference's batch-global early exit")
+    ap.add_argument("--device-channel", action="store_true", help="generate the AWGN samples on the GPU (same RNG draws, device libm)")
     ap.add_argument("--as-written", action="store_true", help="decode on the reference's Transform_H table as written (SURVEY F3)")
     args = ap.parse_args()
 
@@ -60,7 +61,7 @@ def main():
                   "fixed iterations" if args.fixed else "batch-global early exit", args.iters or 50, args.batch, world))
             print("# SNR      NTF   NEF         FER         BER  AverIT       FER_F      FER_A")
         sweep(code, args.start, args.stop, args.step, snrtype=1, dist=dist, Num_Frames_OneTime=args.batch, maxIT=args.iters or 50,
-              exit_mode=C.EXIT_FIXED if args.fixed else C.EXIT_BATCH_GLOBAL, max_batches=args.max_batches, displayStep=10 ** 12,
+              exit_mode=C.EXIT_FIXED if args.fixed else C.EXIT_BATCH_GLOBAL, max_batches=args.max_batches, displayStep=10 ** 12, device_channel=args.device_channel,
               log=print if rank == 0 else None)
     else:
         from cuda_ldpc_amd import nbldpc as nb
