@@ -380,7 +380,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     // row j = jq + rr*GJ, this thread's edges pp = h*WCH + i
     const int rbase = ((jq * WC + h * WCH) * Z + t) * MSG;   // + (rr*GJ*WC + i)*Z*MSG
     const int sbase = (GM::Sslot + cg * Z + t) * MSG;        // + cc*NCG*Z*MSG
-    unsigned saddr[RPT][(WCH + 1) / 2];
+    int saddr[RPT][WCH]; // byte addresses of the S values of this thread's edges
     int e0v[RPT], wrv[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
@@ -400,8 +400,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             int c = t + ed[i].shift;
             c = (c >= Z) ? c - Z : c;
             const int slot = (h * WCH + i < wrv[rr]) ? GM::Sslot + ed[i].col * Z + c : GM::inf_slot;
-            if (i & 1) saddr[rr][i / 2] |= (unsigned)slot << 16;
-            else saddr[rr][i / 2] = (unsigned)slot;
+            saddr[rr][i] = slot * MSG;
             const float zero[NF] = {};
             lds_st<NF>(lds, rbase + (rr * GJ * WC + i) * Z * MSG, zero);
         }
@@ -475,10 +474,6 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     };
 
     for (int it = 1; it < a.max_iter; it++) {
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-            for (int i = 0; i < (WCH + 1) / 2; i++) asm volatile("" : "+v"(saddr[rr][i]));
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
@@ -497,8 +492,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 float Sv[WCH][NF], Rv[WCH][NF];
 #pragma unroll
                 for (int i = 0; i < WCH; i++) {
-                    const unsigned pk = saddr[rr][i / 2];
-                    lds_ld<NF>(Sv[i], lds, (int)((i & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
+                    lds_ld<NF>(Sv[i], lds, saddr[rr][i]);
                     lds_ld<NF>(Rv[i], lds, rbase + (rr * GJ * WC + i) * Z * MSG);
                 }
 #pragma unroll
