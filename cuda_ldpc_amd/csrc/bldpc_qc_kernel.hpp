@@ -111,7 +111,7 @@ template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int G_, int MINW_> 
 // once, in the prologue.
 template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc(QcArgs a)
 {
-    constexpr int NF = GM::NF, J = GM::J, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, G = GM::G;
+    constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, G = GM::G;
     constexpr int RPT = GM::RPT, CPT = GM::CPT, MSG = GM::MSG;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-aware workgroup id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a

@@ -279,3 +279,26 @@ def test_device_channel_same_draws_as_host(C, orc):
     a = C.AWGNChannel_CPU(s1, 0.5, N, 8, CodeWord=cw)
     b = C.AWGNChannel_GPU(s2, 0.5, N, 8, CodeWord=torch.from_numpy(cw).cuda()).cpu().numpy()
     assert np.abs(a - b).max() < 1e-6
+
+
+def test_reference_signature_shim_cpp_harness(C, tmp_path):
+    """A C++ harness in the reference's calling style drives LDPC_Decoder_GPU (reference signature, shim/) end to end:
+    the hashes SURVEY 8c recorded from the reference kernels come out (corrected table and table as written)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from cuda_ldpc_amd._lib import SO_PATH
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    exe = str(tmp_path / "ref_style_harness")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "shim"),
+                           os.path.join(root, "tests", "cpp", "ref_style_harness.cpp"), os.path.join(root, "shim", "ldpc_ref_shim.hip"),
+                           "-o", exe, "-L", os.path.dirname(SO_PATH), "-lcuda_ldpc_amd", "-Wl,-rpath," + os.path.dirname(SO_PATH)])
+    m = _path(4, 24, 96)
+    out = subprocess.check_output([exe, m, "4", "24", "96", "32", "3.0", "0"]).decode()
+    assert "hash=05a41534 iteraTime=50 flags=31/32" in out, out
+    out = subprocess.check_output([exe, m, "4", "24", "96", "32", "4.0", "0"]).decode()
+    assert "hash=99f71dc5 iteraTime=6 flags=32/32" in out, out
+    out = subprocess.check_output([exe, m, "4", "24", "96", "32", "4.0", "1"]).decode()
+    assert "hash=90c5df9b iteraTime=50" in out, out
