@@ -154,3 +154,13 @@ def test_c_program_links_against_the_abi(C, orc, tmp_path):
     assert "Wc=20 Wv=4" in out and ("addrsum=%d" % int(oc.addr.astype(np.int64).sum())) in out
     assert "y0=0.865149975" in out            # SURVEY Appendix D.3 anchor (Es/N0 3 dB)
     assert "mul[2][33]=" in out and "can not open file" in out
+
+
+def test_nb_matrix_with_zero_coefficient_is_rejected(nbm):
+    """LDPC_N576_K288_GF64_d1_exp.txt stores EXPONENTS (0 = alpha^0), which the reference reads as field elements:
+    an edge with coefficient 0 multiplies every symbol to 0 (and codeword_test.h is not a codeword of that file,
+    SURVEY F8).  The library refuses such a graph loudly instead of decoding a degenerate code (validation runs
+    before any device allocation, so this needs no GPU)."""
+    mul, _, _ = nbm.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    with pytest.raises(Exception, match="coefficient 0"):
+        nbm.NBCode(os.path.join(NB, "LDPC_N576_K288_GF64_d1_exp.txt"), mul)

@@ -180,3 +180,4 @@ def test_nb_simulation_counts_match_reference_style_loop(nb, code, ocode, orc):
         errf += 1 if e else 0
     assert (SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration) == (frames, errf, errb, its)
     assert np.array_equal(seed, oseed)
+
