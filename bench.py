@@ -77,6 +77,27 @@ def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
                       % (nframes, iters, dt)}
 
 
+def pmc_onchip(kernel_name, kern_ms):
+    """On-chip utilisation of the dominant kernel from the committed SQ counter pass (profiles/*_pmc.json "sq"):
+    the fused kernels are bound by the VALU issue rate and the LDS pipe, not by HBM, so this is the roofline that
+    says how far they are from their own ceiling.  VALU: wave-instructions * 2 cycles / (1024 SIMDs); LDS: array-active
+    cycles / (256 CUs); both over the kernel's cycles at the clock the counters saw (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        sq = j.get("sq") or {}
+        if j.get("kernel") != kernel_name or "SQ_INSTS_VALU" not in sq:
+            continue
+        cycles = j["avg_ms"] * 1e-3 * 2.3e9 if not sq.get("GRBM_GUI_ACTIVE") else sq["GRBM_GUI_ACTIVE"] / 8.0
+        return {"valu_issue_util": sq["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cycles, "lds_array_util": sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles,
+                "lds_bank_conflict_cycles": sq.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.basename(p),
+                "note": "profiled pass; kernel cycles from %s" % ("GRBM_GUI_ACTIVE/8" if sq.get("GRBM_GUI_ACTIVE") else "avg_ms * 2.3 GHz")}
+    return None
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
     written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command); None when
@@ -176,7 +197,8 @@ def run_nb(args, rank, world, dev, dist):
         "config": {"workload": "myNBLDPC BDS N576_K288 GF(64) EMS(Nm=2,Nc=2) batch=%d codewords/GPU Eb/N0=%.1fdB" % (frames, snr),
                    "kernel": "nb_ems<q64> one frame per workgroup", "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("nb_ems<q64> one frame per workgroup"), "kernel": "k_nb_ems<64>", "kernel_ms": kern_ms,
+                     "traffic": pmc_traffic("k_nb_ems<64>"), "kernel": "k_nb_ems<64>", "kernel_ms": kern_ms,
+                     "onchip": pmc_onchip("k_nb_ems<64>", kern_ms),
                      "algorithmic_bytes_per_launch": alg_bytes},
         "stats": {"frames": n_all, "error_frames": c[0], "symbol_errors": c[1], "FER": c[0] / n_all, "SER": c[1] / n_all / code.N,
                   "mean_iterations": c[2] / n_all},
@@ -301,7 +323,7 @@ def main():
                        "kernel": code.last_kernel, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(code.last_kernel), "kernel": code.last_kernel, "kernel_ms": kern_ms, "decode_call_ms": call_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "model": model},
+                         "algorithmic_bytes_per_launch": alg_bytes, "model": model, "onchip": pmc_onchip(code.last_kernel, kern_ms)},
             "stats": {"frames": frames * world * args.steps, "error_frames": c[0], "error_bits": c[1],
                       "FER": c[0] / (frames * world * args.steps), "BER": c[1] / (frames * world * args.steps) / code.K},
         }
