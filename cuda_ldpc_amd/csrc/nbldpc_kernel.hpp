@@ -89,15 +89,18 @@ template <int K, int J> __device__ __forceinline__ void nb_bitonic_step(uint32_t
                  : "v"(phi), "v"(plo), "s"(KM)
                  : "vcc");
 }
-template <int K, int J> __device__ __forceinline__ void nb_bitonic_merge(uint32_t &hi, uint32_t &lo)
+// W independent sorts advance through the network together: each step waits ~an LDS round trip for its
+// partner keys, so one sort alone is latency-bound; W of them fill that latency with each other's work.
+template <int K, int J, int W> __device__ __forceinline__ void nb_bitonic_merge(uint32_t (&hi)[W], uint32_t (&lo)[W])
 {
-    nb_bitonic_step<K, J>(hi, lo);
-    if constexpr (J > 1) nb_bitonic_merge<K, J / 2>(hi, lo);
+#pragma unroll
+    for (int i = 0; i < W; i++) nb_bitonic_step<K, J>(hi[i], lo[i]);
+    if constexpr (J > 1) nb_bitonic_merge<K, J / 2, W>(hi, lo);
 }
-template <int K> __device__ __forceinline__ void nb_bitonic_sort(uint32_t &hi, uint32_t &lo)
+template <int K, int W> __device__ __forceinline__ void nb_bitonic_sort(uint32_t (&hi)[W], uint32_t (&lo)[W])
 {
-    if constexpr (K > 2) nb_bitonic_sort<K / 2>(hi, lo);
-    nb_bitonic_merge<K, K / 2>(hi, lo);
+    if constexpr (K > 2) nb_bitonic_sort<K / 2, W>(hi, lo);
+    nb_bitonic_merge<K, K / 2, W>(hi, lo);
 }
 
 template <int NACT> struct NbCn {
@@ -324,24 +327,32 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
             break;
         }
         // ---- B: stable descending sort of every v2c vector (:17-36, :253-269) -----------------
-        for (int edge = wave; edge < NE; edge += nwaves) {
-            const int col = edge / dv, d = edge - col * dv;
-            if (d >= t_vn_w[col]) continue;
-            const int h = t_vn_gf[edge];
-            const float val = (lane < q) ? pairs[edge * PST + 2 * lane] : 0.0f;
-            // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
-            const uint32_t b = __float_as_uint(val + 0.0f);
-            const uint32_t ua = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
-            // stable descending order = descending order of the distinct keys (value image, 63 - index)
-            uint32_t khi = ua, klo = 63u - (unsigned)lane;
-            if (!(NB_ABLATE & 2)) nb_bitonic_sort<64>(khi, klo);
-            const int idx = 63 - (int)klo; // original position of the element that belongs at position `lane`
-            if (lane < q) {
-                const int symk = (idx < q - 1) ? idx + 1 : 0;
-                float2 pr;
-                pr.x = pairs[edge * PST + 2 * idx];
-                pr.y = __int_as_float((int)mulb[symk * q + h]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
-                *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * lane) = pr;
+        constexpr int SW = 4; // sorts in flight per wave
+        for (int e0 = wave * SW; e0 < NE; e0 += nwaves * SW) {
+            uint32_t khi[SW], klo[SW];
+            bool live[SW];
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+                const int edge = e0 + i;
+                live[i] = edge < NE && (edge % dv) < t_vn_w[edge / dv];
+                const float val = (live[i] && lane < q) ? pairs[edge * PST + 2 * lane] : 0.0f;
+                // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
+                const uint32_t b = __float_as_uint(val + 0.0f);
+                khi[i] = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
+                klo[i] = 63u - (unsigned)lane; // stable descending order = descending order of the distinct keys
+            }
+            if (!(NB_ABLATE & 2)) nb_bitonic_sort<64, SW>(khi, klo);
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+                const int edge = e0 + i;
+                if (live[i] && lane < q) {
+                    const int idx = 63 - (int)klo[i]; // original position of the element that belongs at position `lane`
+                    const int symk = (idx < q - 1) ? idx + 1 : 0;
+                    float2 pr;
+                    pr.x = pairs[edge * PST + 2 * idx];
+                    pr.y = __int_as_float((int)mulb[symk * q + t_vn_gf[edge]]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
+                    *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * lane) = pr;
+                }
             }
         }
         __syncthreads();
