@@ -118,6 +118,14 @@ static int up(void **dst, const void *src, size_t bytes)
     return NBLDPC_OK;
 }
 
+using NbKernel = void (*)(NbArgs);
+static NbKernel nb_kernel(int q, int dv)
+{
+    if (q == 64) return dv <= 2 ? k_nb_ems<64, 2> : k_nb_ems<64, kNbMaxDv>;
+    if (q == 32) return dv <= 2 ? k_nb_ems<32, 2> : k_nb_ems<32, kNbMaxDv>;
+    return dv <= 2 ? k_nb_ems<16, 2> : k_nb_ems<16, kNbMaxDv>;
+}
+
 static size_t nb_lds_bytes(int N, int M, int q, int dv, int dc)
 {
     return ((size_t)N * dv * nb_pair_stride(q) + (size_t)q * (M * dc + 1) + N + 4) * sizeof(float) + (size_t)q * q +
@@ -181,9 +189,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     if (!r) r = up((void **)&c->d_mul, mulb.data(), mulb.size());
     if (!r) {
         hipError_t e = hipSuccess;
-        if (q == 64) e = hipFuncSetAttribute((const void *)k_nb_ems<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (q == 32) e = hipFuncSetAttribute((const void *)k_nb_ems<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (q == 16) e = hipFuncSetAttribute((const void *)k_nb_ems<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     if (r) { nbldpc_code_destroy(c); return r; }
@@ -214,9 +220,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     a.N = c->N; a.M = c->M; a.q = c->q; a.dv = c->dv; a.dc = c->dc; a.B = B; a.Nm = Nm; a.Nc = Nc; a.max_iter = maxIT;
     a.dcmax_cfg = maxdc_cfg > 0 ? maxdc_cfg : c->dc;
     hipStream_t st = (hipStream_t)stream;
-    if (c->q == 64) hipLaunchKernelGGL(k_nb_ems<64>, dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
-    else if (c->q == 32) hipLaunchKernelGGL(k_nb_ems<32>, dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
-    else hipLaunchKernelGGL(k_nb_ems<16>, dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
+    hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }

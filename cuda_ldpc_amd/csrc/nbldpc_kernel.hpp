@@ -243,7 +243,8 @@ __device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, cons
     nb_conf<0, NACT>(c, 0, 0, a.Nm, Nc);     // ConstructConf(EMS_Nm, EMS_Nc) :300
 }
 
-template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a)
+// Q: field size (= lanes used per vector); DVM: bound on the column weight (loops over a node's edges are unrolled to it)
+template <int Q, int DVM> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int frame = blockIdx.x;
@@ -289,9 +290,9 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
         for (int col = wave; col < N; col += nwaves) {
             const int w = t_vn_w[col];
             float llr = active ? Lch[col * (q - 1) + lane] : 0.0f;
-            float c2[kNbMaxDv];
+            float c2[DVM];
 #pragma unroll
-            for (int d = 0; d < kNbMaxDv; d++) {
+            for (int d = 0; d < DVM; d++) {
                 c2[d] = 0.0f;
                 if (d < w) {
                     const int thr = t_vn_thr[col * dv + d], h = t_vn_gf[col * dv + d];
@@ -310,7 +311,7 @@ template <int Q> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a
             if (lane == 0) outs[col] = dec;
             if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
 #pragma unroll
-            for (int d = 0; d < kNbMaxDv; d++)
+            for (int d = 0; d < DVM; d++)
                 if (d < w && lane < q) pairs[(col * dv + d) * PST + 2 * lane] = active ? llr - c2[d] : 0.0f; // :241-251
         }
         __syncthreads();
