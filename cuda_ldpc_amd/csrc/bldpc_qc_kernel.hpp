@@ -796,8 +796,7 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     unsigned long long *hist = flag_hist ? flag_hist : hist_ws;
     int r = qc_launch(q, y, F, max_iter, length, D, app, hist, bits, st, ev0, ev1);
     if (r) return r;
-    const unsigned long long ones = ~0ull;
-    CLDPC_HIP(hipMemcpyAsync(and_ws, &ones, sizeof(ones), hipMemcpyHostToDevice, st), BLDPC_EHIP);
+    CLDPC_HIP(hipMemsetAsync(and_ws, 0xFF, sizeof(unsigned long long), st), BLDPC_EHIP);
     hipLaunchKernelGGL(k_hist_and, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, hist, F, and_ws);
     unsigned long long all = 0;
     CLDPC_HIP(hipMemcpyAsync(&all, and_ws, sizeof(all), hipMemcpyDeviceToHost, st), BLDPC_EHIP);

@@ -43,7 +43,10 @@ extern "C" {
 #define BLDPC_KERNEL_TABLE 1  /* generic address-table kernels, messages resident in HBM; any table      */
 #define BLDPC_KERNEL_QC_LDS 2 /* fused QC kernel, all iterations on-chip, messages resident in LDS       */
 
-typedef struct bldpc_code bldpc_code; /* opaque: device-resident code tables + cached workspace */
+typedef struct bldpc_code bldpc_code; /* opaque: device-resident code tables + cached workspace.  A code object owns
+                                        * its scratch buffers: use it from one host thread / one stream at a time (create
+                                        * one object per concurrent stream, like a BLAS handle); different objects are
+                                        * independent. */
 
 /* -- graph builders ------------------------------------------------------- */
 
