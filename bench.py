@@ -37,6 +37,10 @@ WORKLOADS = {
     "J4_L24_Z96": ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 65536, 3.0, 50),
     "J32_L64_Z64": ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 32768, 0.0, 50),
     "J15_L30_Z1280": ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, 1024, 0.0, 50),
+    # further matrices of the reference (not BASELINE configs): its compiled-in default (define.cuh:20-22) and one per family
+    "PON_J12_L69_Z256": ("PON_LDPC.txt", 12, 69, 256, 8192, 2.0, 50),
+    "J10_L60_Z160": ("J10_L60_Z160_BlockH.txt", 10, 60, 160, 16384, 2.5, 50),
+    "J4_L24_Z512": ("J4_L24_Z512_BlockH.txt", 4, 24, 512, 8192, 3.0, 50),
     # GF(64) EMS (BASELINE.json configs[4]): frames per GPU, Eb/N0 dB, maxIT (reference default 20, define.h:35)
     "NB_BDS_GF64": ("BDS.576.288.GF.64.txt", 0, 0, 0, 16384, 3.0, 20),
 }

@@ -40,6 +40,7 @@
 
 #include "../../include/bldpc.h"
 #include "bldpc_math.hpp"
+#include "bldpc_qcc_kernel.hpp"
 #include "common.hpp"
 
 #ifndef QC_ABLATE
@@ -62,6 +63,10 @@ struct QcArgs {
     const QcVnEdge *vn_edges;   // [L][WV]
     const unsigned char *wv;    // [L]
     int F, nWG, max_iter, length;
+    // compressed-state kernel (k_qcc) only:
+    const unsigned *cn_meta;    // [J][WCS] padded row slots
+    const unsigned *vn_meta;    // [L][WVS] column edges, top -> bottom
+    int J, L, WVS;
 };
 
 template <int NF> struct Msg;
@@ -609,6 +614,167 @@ __global__ __launch_bounds__(256) void k_expand_bits(const unsigned *bits, int *
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Compressed-state kernel, see bldpc_qcc_kernel.hpp.  LDS: mm float2[M] | w2 uint[M] | S float[(L+1)*Z] | flag.
+template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_qcc(QcArgs a)
+{
+    constexpr int Z = GM::Z, U = GM::U, G = GM::G, CPT = GM::CPT, WCS = GM::WCS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
+    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (wg >= a.nWG) return;
+    const int J = a.J, L = a.L, M = J * Z, N = L * Z, F = a.F;
+    const int tid = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(tid / U); // wave-uniform
+    const int t0 = tid - g * U;
+    const bool lane_on = t0 < Z;      // the surplus lanes of the padded group idle
+    const int t = lane_on ? t0 : 0;   // ... on valid addresses
+    const int off_w2 = M * 8, off_S = M * 12;
+    int *lds_flag = reinterpret_cast<int *>(lds + off_S + (L + 1) * Z * 4);
+    const int f = wg; // one frame per workgroup
+
+    // ---- prologue -----------------------------------------------------------------------------------------
+    for (int j = g; j < J; j += G)
+        if (lane_on) {
+            const float zero2[2] = {0.0f, 0.0f}; // min1 = min2 = 0, no signs: every R starts as +0 (LDPC_Decoder.cu:82)
+            lds_st<2>(lds, (j * Z + t) * 8, zero2);
+            const float zw[1] = {0.0f};
+            lds_st<1>(lds, off_w2 + (j * Z + t) * 4, zw);
+        }
+    if (g == 0 && lane_on) {
+        const float inf[1] = {__builtin_inff()};
+        lds_st<1>(lds, off_S + (L * Z + t) * 4, inf); // padding column: neutral for min1/min2/sign
+    }
+    float yreg[CPT];
+    int wcol[CPT];
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) {
+        const int l = g + cc * G;
+        wcol[cc] = (l < L) ? a.wv[l] : 0;
+        yreg[cc] = (l < L && lane_on) ? a.y[(size_t)f * N + l * Z + t] : 0.0f;
+    }
+    if (tid == 0) lds_flag[0] = 0;
+    unsigned long long hist = 0;
+    __syncthreads();
+
+    auto vn_phase = [&](bool &bad) {
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            const int l = g + cc * G;
+            if (l < L) { // wave-uniform
+                float S = 0.0f;
+                const unsigned *vm = a.vn_meta + l * a.WVS;
+#pragma unroll 4
+                for (int k = 0; k < wcol[cc]; k++) {
+                    const unsigned m = vm[k]; // scalar load
+                    const int j = m & 63, pos = (m >> 6) & 31, sh = m >> 11;
+                    int r = t - sh;
+                    r = (r < 0) ? r + Z : r;
+                    const int sidx = j * Z + r;
+                    float mm[2], w2f[1];
+                    lds_ld<2>(mm, lds, sidx * 8);
+                    lds_ld<1>(w2f, lds, off_w2 + sidx * 4);
+                    S += qcc_recon(mm[0], mm[1], f2u(w2f[0]), pos); // ascending block row = the reference's edge order
+                }
+                S += yreg[cc];
+                if (lane_on) {
+                    const float sv[1] = {S};
+                    lds_st<1>(lds, off_S + (l * Z + t) * 4, sv);
+                    if (HIST) bad = bad || ((l * Z + t) < a.length && S < 0);
+                }
+            }
+        }
+    };
+    auto flags_collect = [&](int it) -> int {
+        int flag = 0;
+        if (tid == 0) {
+            flag = lds_flag[0] ? 0 : 1;
+            lds_flag[0] = 0;
+            if (flag && it <= 64) hist |= (1ull << (it - 1));
+        }
+        return flag;
+    };
+
+    for (int it = 1; it < a.max_iter; it++) {
+        bool bad = false;
+        vn_phase(bad);
+        if (HIST && bad) lds_flag[0] = 1;
+        __syncthreads();
+        if (HIST) (void)flags_collect(it);
+
+        // CN phase (LDPC_Decoder.cu:279-314) on the compressed state
+        for (int j = g; j < J; j += G) { // wave-uniform
+            const int sidx = j * Z + t;
+            float pm[2], pw[1];
+            lds_ld<2>(pm, lds, sidx * 8);
+            lds_ld<1>(pw, lds, off_w2 + sidx * 4);
+            const unsigned pw2 = f2u(pw[0]);
+            const unsigned *cm = a.cn_meta + j * WCS;
+            const int w = a.rowptr[j + 1] - a.rowptr[j];
+            float Sv[WCS];
+#pragma unroll
+            for (int p = 0; p < WCS; p++) {
+                const unsigned m = cm[p]; // scalar load; padding slots point at the +inf column with shift 0
+                const int col = m & 255, sh = m >> 8;
+                int c = t + sh;
+                c = (c >= Z) ? c - Z : c;
+                float sv[1];
+                lds_ld<1>(sv, lds, off_S + (col * Z + c) * 4);
+                Sv[p] = sv[0];
+            }
+            float m1 = __builtin_inff(), m2 = __builtin_inff();
+            unsigned signs = 0;
+            int idx = 0;
+#pragma unroll
+            for (int p = 0; p < WCS; p++) {
+                const float q = Sv[p] - qcc_recon(pm[0], pm[1], pw2, p); // Q = S - R  (LDPC_Decoder.cu:206-209)
+                const float aq = __builtin_fabsf(q);
+                idx = (aq < m1) ? p : idx;                       // first edge holding the minimum (:298-305)
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, aq);
+                m1 = __builtin_fminf(m1, aq);
+                signs |= (f2u(q) >> 31) << p;
+            }
+            // R_p = Sign[25]*Sign[p] * magnitude: output sign bit p = parity of all signs XOR sign p
+            if (__builtin_popcount(signs) & 1) signs ^= (1u << w) - 1u;
+            if (lane_on) {
+                const float nm[2] = {m1, m2};
+                lds_st<2>(lds, sidx * 8, nm);
+                const float nw[1] = {u2f(signs | ((unsigned)idx << 27))};
+                lds_st<1>(lds, off_w2 + sidx * 4, nw);
+            }
+        }
+        __syncthreads();
+    }
+
+    {
+        bool bad = false;
+        vn_phase(bad);
+        bad = false;
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            const int l = g + cc * G;
+            if (l < L) {
+                const int n = l * Z + t;
+                float sv[1];
+                lds_ld<1>(sv, lds, off_S + n * 4);
+                const bool neg = lane_on && sv[0] < 0;
+                bad = bad || (n < a.length && neg);
+                const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave (Z % 32 == 0)
+                if ((tid & 31) == 0 && lane_on) a.bits[(size_t)f * (N / 32) + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (a.app && lane_on) a.app[(size_t)n * F + f] = sv[0];
+            }
+        }
+        if (bad) lds_flag[0] = 1;
+        __syncthreads();
+        const int flag = flags_collect(a.max_iter);
+        if (tid == 0) {
+            a.D[(size_t)N * F + f] = flag;
+            if (HIST && a.hist) a.hist[f] = hist;
+        }
+    }
+}
+
 // AND of all frames' flag histories -> first iteration at which every frame's flag is set.
 __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist, int F, unsigned long long *out)
 {
@@ -620,7 +786,8 @@ __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist
 
 // ---------------------------------------------------------------------------------------------
 using QcKernel = void (*)(QcArgs);
-struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; };
+struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; int U, CPT; };
+// tag "compressed": J = L = 0 (any), WC = row slots, lds_bytes computed per code
 
 // Ahead-of-time variants: one per block-matrix geometry of the reference's matrix set whose message
 // state fits one CU's LDS (shifts are run-time data, so every code of the same J x L x Z shape and
@@ -639,19 +806,28 @@ inline const QcVariant *qc_variants(int *count)
 #define X(NF, J, L, Z, WC, WV, G, MINW)                                                                  \
     {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW>::TPB,                              \
      QcGeom<NF, J, L, Z, WC, WV, G, MINW>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, false>,    \
-     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>, "row"},
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>, "row", 0, 0},
 #define X2(NF, J, L, Z, WC, WV, GJ, MINW)                                                                 \
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::TPB,                            \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, false>, \
-     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow"},
+     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow", 0, 0},
+#define XC(Z, U, G, CPT, WCS)                                                                              \
+    {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
+     k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT},
     static const QcVariant v[] = {
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
         X2(2, 12, 24, 96, 8, 6, 4, 3) /* J12_L24_Z96 (rows padded 7 -> 8): 768 thr, 92 KB                        */
         X2(2, 6, 24, 96, 16, 4, 3, 3) /* J6_L24_Z96 (rows padded 15 -> 16): 576 thr, 92 KB                       */
-        QC_VARIANTS(X)};
+        QC_VARIANTS(X)
+        /* compressed check state (bldpc_qcc_kernel.hpp): any J, L with ceil(L/G) <= CPT and row weight <= WCS */
+        XC(256, 256, 4, 18, 24) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22)       */
+        XC(160, 192, 5, 12, 24) /* the Z = 160 family, J10 ... J48, L60                                   */
+        XC(512, 512, 2, 12, 24) /* J4_L24_Z512                                                            */
+    };
 #undef X
 #undef X2
+#undef XC
     *count = (int)(sizeof(v) / sizeof(v[0]));
     return v;
 }
@@ -666,6 +842,8 @@ struct QcPlan {
     unsigned short *d_rowptr = nullptr;
     QcVnEdge *d_vn = nullptr;
     unsigned char *d_wv = nullptr;
+    unsigned *d_cn_meta = nullptr, *d_vn_meta = nullptr; // compressed-state kernel
+    int WVS = 0, lds_bytes = 0;
     char name[96] = "qc_lds(unavailable)";
 };
 
@@ -675,6 +853,9 @@ inline void qc_plan_release(QcPlan *q)
     if (q->d_rowptr) (void)hipFree(q->d_rowptr);
     if (q->d_vn) (void)hipFree(q->d_vn);
     if (q->d_wv) (void)hipFree(q->d_wv);
+    if (q->d_cn_meta) (void)hipFree(q->d_cn_meta);
+    if (q->d_vn_meta) (void)hipFree(q->d_vn_meta);
+    q->d_cn_meta = nullptr; q->d_vn_meta = nullptr;
     q->d_cn = nullptr; q->d_rowptr = nullptr; q->d_vn = nullptr; q->d_wv = nullptr;
     q->frames_per_wg = 0;
 }
@@ -708,19 +889,42 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     for (int vi = 0; vi < nvar && q->variant < 0; vi++) {
         const QcVariant &v = vars[vi];
         if (pin && atoi(pin) != vi) continue;
-        if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.WV < Wv) continue;
-        if ((size_t)v.lds_bytes > kLdsBytes) continue;
+        if (v.U) { // compressed-state kernel: geometry-generic
+            const size_t lds = (size_t)J * Z * 12 + (size_t)(L + 1) * Z * 4 + 16;
+            if (v.Z != Z || (L + v.G - 1) / v.G > v.CPT || v.WC < Wc || Wv > 31 || J > 63 || L > 254 || Z > 2047 || lds > kLdsBytes) continue;
+            q->lds_bytes = (int)lds;
+        } else {
+            if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.WV < Wv) continue;
+            if ((size_t)v.lds_bytes > kLdsBytes) continue;
+            q->lds_bytes = v.lds_bytes;
+        }
         q->variant = vi;
     }
     if (q->variant < 0) return BLDPC_OK;
     const QcVariant &v = vars[q->variant];
-    std::vector<QcVnEdge> vn((size_t)L * v.WV, QcVnEdge{0, 0});
+    if (v.U) { // meta tables of the compressed-state kernel
+        q->WVS = Wv;
+        std::vector<unsigned> cm((size_t)J * v.WC, qcc_cn_meta(L, 0)), vm((size_t)L * Wv, 0u);
+        std::vector<int> fillc(L, 0);
+        for (int j = 0; j < J; j++)
+            for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
+                const int pos = e - rowptr[j], l = cn[e].col;
+                cm[(size_t)j * v.WC + pos] = qcc_cn_meta(l, cn[e].shift);
+                vm[(size_t)l * Wv + fillc[l]++] = qcc_vn_meta(j, pos, cn[e].shift); // ascending j = the reference's edge order
+            }
+        CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
+        CLDPC_HIP(hipMalloc((void **)&q->d_vn_meta, vm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
+        CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+        CLDPC_HIP(hipMemcpy(q->d_vn_meta, vm.data(), vm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+    }
+    const int vnw = v.U ? 1 : v.WV;
+    std::vector<QcVnEdge> vn((size_t)L * vnw, QcVnEdge{0, 0});
     std::vector<int> fill(L, 0);
     for (int j = 0; j < J; j++)
         for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
             const int l = cn[e].col;
             // ascending j = the reference's edge order; .e = padded block index row*WC + position
-            vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift};
+            if (!v.U) vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift};
         }
     std::vector<unsigned char> wvb(L);
     for (int l = 0; l < L; l++) wvb[l] = (unsigned char)wv[l];
@@ -732,11 +936,11 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     CLDPC_HIP(hipMemcpy(q->d_rowptr, rowptr.data(), rowptr.size() * sizeof(unsigned short), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipMemcpy(q->d_vn, vn.data(), vn.size() * sizeof(QcVnEdge), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipMemcpy(q->d_wv, wvb.data(), wvb.size(), hipMemcpyHostToDevice), BLDPC_EHIP);
-    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
-    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
+    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.U ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
+    CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, v.U ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
     q->frames_per_wg = v.NF;
-    snprintf(q->name, sizeof(q->name), "qc_lds_%s<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.tag, v.NF, v.J, v.L, v.Z, v.WC, v.WV,
-             v.G, v.MINW, v.threads, v.lds_bytes);
+    snprintf(q->name, sizeof(q->name), "qc_lds_%s<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.tag, v.NF, J, L, v.Z, v.WC, v.U ? Wv : v.WV,
+             v.G, v.MINW, v.threads, q->lds_bytes);
     return BLDPC_OK;
 }
 
@@ -744,7 +948,7 @@ inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStre
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
-    const int N = v.L * v.Z;
+    const int N = q->L * q->Z;
     const dim3 grid((unsigned)((F + 63) / 64), (unsigned)((N + 63) / 64));
     if (v.NF == 2) hipLaunchKernelGGL(k_regroup_y<2>, grid, dim3(256), 0, st, y, yg, N, F);
     else hipLaunchKernelGGL(k_regroup_y<1>, grid, dim3(256), 0, st, y, yg, N, F);
@@ -764,11 +968,12 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     a.F = F;
     a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
     a.max_iter = max_iter; a.length = length;
+    a.cn_meta = q->d_cn_meta; a.vn_meta = q->d_vn_meta; a.J = q->J; a.L = q->L; a.WVS = q->WVS;
     const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), v.lds_bytes, st, a);
+    hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
-    const int NW = v.L * v.Z / 32;
+    const int NW = q->L * q->Z / 32;
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
