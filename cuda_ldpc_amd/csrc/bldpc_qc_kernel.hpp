@@ -41,7 +41,6 @@
 #include "../../include/bldpc.h"
 #include "bldpc_math.hpp"
 #include "bldpc_qcc_kernel.hpp"
-#include "bldpc_qcr_kernel.hpp"
 #include "common.hpp"
 
 #ifndef QC_ABLATE
@@ -776,178 +775,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Register-state kernel for long blocks, see bldpc_qcr_kernel.hpp.  LDS: S float[N] | flag.
-template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_qcr(QcArgs a)
-{
-    constexpr int J = GM::J, Z = GM::Z, TPB = GM::TPB, WCS = GM::WCS, ZR = GM::ZR, MINW = GM::MINW;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
-    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (wg >= a.nWG) return;
-    const int N = a.L * Z, F = a.F;
-    const int tid = threadIdx.x;
-    const int f = wg; // one frame per workgroup
-    const float *yf = a.y + (size_t)f * N;
-    int *lds_flag = reinterpret_cast<int *>(lds + N * 4);
-
-    float m1[J][ZR], m2[J][ZR]; // check states: R_p = +-m1, +-m2 on edge idx
-    unsigned w2[J][ZR];         // idx << 27 | output sign bits
-#pragma unroll
-    for (int j = 0; j < J; j++)
-#pragma unroll
-        for (int z = 0; z < ZR; z++) {
-            m1[j][z] = 0.0f; m2[j][z] = 0.0f; w2[j][z] = 0u; // every R starts as +0 (LDPC_Decoder.cu:82)
-        }
-    bool bad = false;
-    for (int v = tid; v < N; v += TPB) { // iteration 1: S = (0 + 0 + ...) + y
-        const float sv[1] = {0.0f + yf[v]};
-        lds_st<1>(lds, v * 4, sv);
-        if (HIST) bad = bad || (v < a.length && sv[0] < 0);
-    }
-    if (tid == 0) lds_flag[0] = 0;
-    unsigned long long hist = 0;
-    __syncthreads();
-    auto flags_collect = [&](int it) -> int {
-        int flag = 0;
-        if (tid == 0) {
-            flag = lds_flag[0] ? 0 : 1;
-            lds_flag[0] = 0;
-            if (flag && it <= 64) hist |= (1ull << (it - 1));
-        }
-        return flag;
-    };
-    if (HIST) {
-        if (bad) lds_flag[0] = 1;
-        __syncthreads();
-        if (a.max_iter > 1) (void)flags_collect(1);
-    }
-
-    // byte address of the S value behind row slot m for circulant position t: column base + (t + shift) mod Z
-    auto s_addr = [&](unsigned m, int t) -> int {
-        const unsigned c1 = (unsigned)t + ((m >> 8) & 2047u);
-        const unsigned c = min(c1, c1 - (unsigned)Z); // c1 - Z wraps to a huge value unless c1 >= Z
-        return (int)(((m & 255u) * (unsigned)Z + c) * 4u);
-    };
-    for (int it = 1; it < a.max_iter; it++) {
-        // ---- phase 1: check nodes on S of iteration `it` (LDPC_Decoder.cu:279-314) ----
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-            const unsigned *cm = a.cn_meta + j * WCS; // wave-uniform: scalar loads
-            const int w = a.rowptr[j + 1] - a.rowptr[j];
-            float Sv[ZR][WCS];
-            // slots below MINW exist in every row: straight-line code, all reads of the block row in flight together
-#pragma unroll
-            for (int z = 0; z < ZR; z++)
-#pragma unroll
-                for (int p = 0; p < WCS; p++)
-                    if (p < MINW || p < w) {
-                        float sv[1];
-                        lds_ld<1>(sv, lds, s_addr(cm[p], tid + z * TPB));
-                        Sv[z][p] = sv[0];
-                    }
-#pragma unroll
-            for (int z = 0; z < ZR; z++) {
-                float n1 = __builtin_inff(), n2 = __builtin_inff();
-                unsigned signs = 0;
-                int idx = 0;
-#pragma unroll
-                for (int p = 0; p < WCS; p++)
-                    if (p < MINW || p < w) {
-                        const float q = Sv[z][p] - qcc_recon(m1[j][z], m2[j][z], w2[j][z], p); // Q = S - R (:206-209)
-                        const float aq = __builtin_fabsf(q);
-                        idx = (aq < n1) ? p : idx; // first edge holding the minimum (:298-305)
-                        n2 = __builtin_amdgcn_fmed3f(n1, n2, aq);
-                        n1 = __builtin_fminf(n1, aq);
-                        signs |= (f2u(q) >> 31) << p;
-                    }
-                // R_p = Sign[25]*Sign[p] * magnitude: output sign bit p = parity of all signs XOR sign p
-                if (__builtin_popcount(signs) & 1) signs ^= (1u << w) - 1u;
-                m1[j][z] = n1; m2[j][z] = n2;
-                w2[j][z] = signs | ((unsigned)idx << 27);
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 2: S of iteration it+1 = ((0 + R_0) + R_1 + ...), block rows in ascending order (:188-204) ----
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-            const unsigned *cm = a.cn_meta + j * WCS;
-            const int w = a.rowptr[j + 1] - a.rowptr[j];
-            float acc[ZR][WCS];
-            int va[ZR][WCS];
-#pragma unroll
-            for (int z = 0; z < ZR; z++)
-#pragma unroll
-                for (int p = 0; p < WCS; p++)
-                    if (p < MINW || p < w) {
-                        va[z][p] = s_addr(cm[p], tid + z * TPB);
-                        float sv[1];
-                        lds_ld<1>(sv, lds, va[z][p]);
-                        acc[z][p] = sv[0];
-                    }
-#pragma unroll
-            for (int z = 0; z < ZR; z++)
-#pragma unroll
-                for (int p = 0; p < WCS; p++)
-                    if (p < MINW || p < w) {
-                        const float prev = ((cm[p] >> 19) & 1u) ? 0.0f : acc[z][p]; // a column's first edge starts from 0
-                        const float sv[1] = {prev + qcc_recon(m1[j][z], m2[j][z], w2[j][z], p)};
-                        lds_st<1>(lds, va[z][p], sv);
-                    }
-            __syncthreads();
-        }
-        // ---- ... + y closes every sum (:205): one aligned pass, channel values re-read (L2-resident) ----
-        bad = false;
-        constexpr int YB = 10; // values in flight per batch
-        for (int v0 = tid; v0 < N; v0 += TPB * YB) {
-            float yv[YB], sv[YB][1];
-#pragma unroll
-            for (int i = 0; i < YB; i++) {
-                const int v = v0 + i * TPB;
-                yv[i] = (v < N) ? yf[v] : 0.0f;
-            }
-#pragma unroll
-            for (int i = 0; i < YB; i++) {
-                const int v = v0 + i * TPB;
-                if (v < N) lds_ld<1>(sv[i], lds, v * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < YB; i++) {
-                const int v = v0 + i * TPB;
-                if (v < N) {
-                    sv[i][0] += yv[i];
-                    lds_st<1>(lds, v * 4, sv[i]);
-                    if (HIST) bad = bad || (v < a.length && sv[i][0] < 0);
-                }
-            }
-        }
-        if (HIST && bad) lds_flag[0] = 1;
-        __syncthreads();
-        if (HIST && it + 1 < a.max_iter) (void)flags_collect(it + 1);
-    }
-
-    // ---- outputs from S of iteration max_iter ----
-    {
-        bad = false;
-        for (int n = tid; n < N; n += TPB) {
-            float sv[1];
-            lds_ld<1>(sv, lds, n * 4);
-            const bool neg = sv[0] < 0;
-            bad = bad || (n < a.length && neg);
-            const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave (TPB % 64 == 0)
-            if ((tid & 31) == 0) a.bits[(size_t)f * (N / 32) + (n >> 5)] = (unsigned)(m >> (tid & 32));
-            if (a.app) a.app[(size_t)n * F + f] = sv[0];
-        }
-        if (bad) lds_flag[0] = 1; // (HIST: phase 2 of the last round has already published the same verdict)
-        __syncthreads();
-        const int flag = flags_collect(a.max_iter);
-        if (tid == 0) {
-            a.D[(size_t)N * F + f] = flag;
-            if (HIST && a.hist) a.hist[f] = hist;
-        }
-    }
-}
+#include "bldpc_qcr_kernel.hpp" // k_qcr: check states in registers, S in LDS (long blocks)
 
 // AND of all frames' flag histories -> first iteration at which every frame's flag is set.
 __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist, int F, unsigned long long *out)
@@ -988,9 +816,9 @@ inline const QcVariant *qc_variants(int *count)
 #define XC(Z, U, G, CPT, WCS)                                                                              \
     {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
      k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0},
-#define XR(J, Z, TPB, WCS, MINW)                                                                           \
-    {1, J, 0, Z, WCS, 31, 0, MINW, TPB, 0, k_qcr<QcrGeom<J, Z, TPB, WCS, MINW>, false>,                      \
-     k_qcr<QcrGeom<J, Z, TPB, WCS, MINW>, true>, "regstate", 0, 0, 1},
+#define XR(J, L, Z, TPB, WCS, MINW, YB)                                                                     \
+    {1, J, L, Z, WCS, 31, 0, MINW, TPB, 0, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, false>,               \
+     k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1},
     static const QcVariant v[] = {
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
@@ -1001,8 +829,8 @@ inline const QcVariant *qc_variants(int *count)
         XC(256, 256, 4, 18, 24) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22)       */
         XC(160, 192, 5, 12, 24) /* the Z = 160 family, J10 ... J48, L60                                   */
         XC(512, 512, 2, 12, 24) /* J4_L24_Z512                                                            */
-        /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp): long blocks, any L with 4 N <= LDS */
-        XR(15, 1280, 640, 8, 7) /* J15_L30_Z1280 (BASELINE config 4): 640 thr, 150 KB, 30 states per thread  */
+        /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp): long blocks with 4 N <= LDS */
+        XR(15, 30, 1280, 768, 8, 7, 10) /* J15_L30_Z1280 (BASELINE config 4): 12 waves, 8 of them cover 2 tiles of Z (5 tiles per SIMD) */
     };
 #undef X
 #undef X2
@@ -1070,9 +898,9 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     for (int vi = 0; vi < nvar && q->variant < 0; vi++) {
         const QcVariant &v = vars[vi];
         if (pin && atoi(pin) != vi) continue;
-        if (v.regstate) { // register-state kernel: J, Z fixed; any L whose S array fits LDS
+        if (v.regstate) { // register-state kernel
             const size_t lds = (size_t)L * Z * 4 + 16;
-            if (v.J != J || v.Z != Z || v.WC < Wc || v.MINW > Wcmin || L > 255 || Z > 2047 || lds > kLdsBytes) continue;
+            if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.MINW > Wcmin || L > 255 || Z > 2047 || lds > kLdsBytes) continue;
             q->lds_bytes = (int)lds;
         } else if (v.U) { // compressed-state kernel: geometry-generic
             const size_t lds = (size_t)J * Z * 12 + (size_t)(L + 1) * Z * 4 + 16;
@@ -1087,17 +915,21 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     }
     if (q->variant < 0) return BLDPC_OK;
     const QcVariant &v = vars[q->variant];
-    if (v.regstate) { // row slots with first/last-edge-of-column marks
-        std::vector<unsigned> cm((size_t)J * v.WC, 0u);
+    if (v.regstate) { // row slots with first-edge-of-column marks; block rows rotated until column 0 has shift 0
+        std::vector<unsigned> cm((size_t)J * v.WC, qcr_cn_meta(0, 0, 0, 1));
         std::vector<int> seen(L, 0);
-        for (int j = 0; j < J; j++)
+        bool ok = true;
+        for (int j = 0; j < J && ok; j++) {
+            ok = rowptr[j + 1] > rowptr[j] && cn[rowptr[j]].col == 0; // column 0 must meet every block row (slot 0)
+            const int rot = ok ? cn[rowptr[j]].shift : 0;
             for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
                 const int l = cn[e].col;
                 seen[l]++;
-                cm[(size_t)j * v.WC + (e - rowptr[j])] = qcr_cn_meta(l, cn[e].shift, seen[l] == 1, seen[l] == wv[l]);
+                cm[(size_t)j * v.WC + (e - rowptr[j])] = qcr_cn_meta(l, (cn[e].shift - rot + Z) % Z, seen[l] == 1, 0);
             }
-        for (int l = 0; l < L; l++)
-            if (wv[l] == 0) { q->variant = -1; return BLDPC_OK; } // an unconnected column would keep a stale S
+        }
+        for (int l = 0; l < L; l++) ok = ok && wv[l] > 0; // an unconnected column would keep a stale S
+        if (!ok) { q->variant = -1; return BLDPC_OK; }
         CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
     }

@@ -1,14 +1,15 @@
 // bldpc_qcr_kernel.hpp -- fused QC min-sum kernel for LONG blocks (BLDPC_KERNEL_QC_LDS, third tier):
 // codes whose compressed check states (12 M bytes) do not fit LDS next to the a-posteriori values either,
 // i.e. BASELINE config 4, J15_L30_Z1280 (N = 38 400: 4 N = 150 KB of the CU's 160 KB).
+// Included from the middle of bldpc_qc_kernel.hpp (needs QcArgs, lds_ld / lds_st).
 //
 // Where the state lives.  LDS holds ONE array, the a-posteriori value S of every variable (4 N bytes).  The
 // check states -- (min1, min2) and a word with the index of the minimum edge and the sign bit of every output,
 // from which R_p = +-min1 / +-min2 is rebuilt exactly (bldpc_qcc_kernel.hpp, bldpc_实习/LDPC_Decoder.cu:298-312)
-// -- live in REGISTERS of the thread that owns the check: thread tid owns rows (j, tid + z*TPB) for every block
-// row j, J*Z/TPB states of 3 VGPRs.  Nothing but the channel values (re-read once per iteration, L2-resident) and
-// the packed hard bits touches HBM: 4 N bytes per frame and iteration instead of the 16 E + 8 N of the
-// reference schedule (2.66 MB -> 154 KB at config 4).
+// -- live in REGISTERS of the thread that owns the check: thread tid owns the checks at circulant positions
+// tid + z*TPB of every block row, 3 VGPRs per state.  Nothing but the channel values (re-read once per
+// iteration, L2-resident) and the packed hard bits touches HBM: 4 N bytes per frame and iteration instead of
+// the 16 E + 8 N of the reference schedule (2.66 MB -> 154 KB at config 4).
 //
 // Schedule of one flooding iteration, bit-identical to the reference's two kernels:
 //   phase 1 (check nodes, LDPC_Decoder.cu:279-314): every check reads S of its neighbours through the rotation
@@ -20,23 +21,272 @@
 //           variable is met by at most one edge, so `S[v] = S[v] + R` is race-free and happens in exactly the
 //           reference's order.  A column's first edge stores 0 + R (overwriting the old S, which phase 1 no
 //           longer needs); one aligned pass adds the channel values at the end.
-// The per-edge tables (column, shift, first/last) are wave-uniform: scalar loads.
-#pragma once
-#include "bldpc_math.hpp"
-#include "bldpc_qcc_kernel.hpp"
+// Column 0 stays out of LDS altogether.  The order of the check rows INSIDE a block row is immaterial (checks
+// have no outputs), so the host rotates every block row until its column-0 block has shift 0 (all other shifts of
+// the row move with it); then variable (0, t) meets check (j, t) in every block row j, i.e. only checks owned by
+// the thread that also owns position t: its S and its running sum are registers.
+// The per-edge tables (column, shift, first-edge mark) are wave-uniform scalar loads, fetched one block row ahead.
+// When TPB does not divide Z the last tile of the circulant is covered by the first waves only; those waves run
+// an instantiation of the iteration loop with one more tile than the others (same number of barriers in both).
+// (no includes, no namespace: this file is spliced into namespace cldpc by bldpc_qc_kernel.hpp)
 
-namespace cldpc {
-
-template <int J_, int Z_, int TPB_, int WCS_, int MINW_> struct QcrGeom {
-    static constexpr int J = J_, Z = Z_, TPB = TPB_, WCS = WCS_, ZR = Z / TPB, MINW = MINW_; // every row has >= MINW edges
-    static_assert(Z % TPB == 0 && TPB % 64 == 0 && TPB <= 1024, "threads must tile the circulant in whole waves");
-    static_assert(WCS <= 27, "sign bits and the 5-bit index share one word");
+template <int J_, int L_, int Z_, int TPB_, int WCS_, int MINW_, int YB_> struct QcrGeom {
+    static constexpr int J = J_, L = L_, Z = Z_, TPB = TPB_, WCS = WCS_, ZR = (Z + TPB - 1) / TPB, MINW = MINW_; // every row has >= MINW edges
+    static constexpr int YB = YB_; // channel values per batch of the closing pass
+    static constexpr bool RAGGED = (Z % TPB) != 0;
+    static_assert((L * Z) % (TPB * YB) == 0, "the closing pass runs in whole batches");
+    static_assert(Z % 64 == 0 && TPB % 64 == 0 && TPB <= 1024, "threads must tile the circulant in whole waves");
+    static_assert(WCS <= 27 && MINW >= 2, "sign bits and the 5-bit index share one word; slot 0 is column 0");
 };
 
-// CN slot word: column | shift << 8 | first edge of its column << 19 | last edge of its column << 20 (unused)
-__host__ __device__ inline unsigned qcr_cn_meta(int col, int shift, int first, int last)
+// CN slot word: column | shift << 8 | first edge of its column << 19 | padding slot << 21
+__host__ __device__ inline unsigned qcr_cn_meta(int col, int shift, int first, int pad)
 {
-    return (unsigned)col | ((unsigned)shift << 8) | ((unsigned)first << 19) | ((unsigned)last << 20);
+    return (unsigned)col | ((unsigned)shift << 8) | ((unsigned)first << 19) | ((unsigned)pad << 21);
 }
 
-} // namespace cldpc
+typedef __attribute__((address_space(4))) const unsigned qcr_const_u32;
+
+// Iterations 1 .. max_iter-1 for a wave that covers NZ tiles of the circulant.  S0[z]: a-posteriori value of
+// variable (0, tid + z*TPB), kept in registers across the whole decode.
+template <typename GM, bool HIST, int NZ>
+__device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *lds_flag, const __amdgpu_buffer_rsrc_t yrs,
+                                               float (&S0)[GM::ZR], unsigned long long &hist)
+{
+    constexpr int J = GM::J, Z = GM::Z, TPB = GM::TPB, WCS = GM::WCS, MINW = GM::MINW, N = GM::L * Z, NS = N / TPB, YB = GM::YB;
+    const int tid = threadIdx.x;
+    // row slots, wave-uniform; read through the constant address space so that they are scalar loads whatever the
+    // compiler can or can not prove about the kernel's own stores
+    const qcr_const_u32 *cm = (const qcr_const_u32 *)a.cn_meta;
+    const int dummy = tid * 4; // column 0's (unused) LDS words take the writes of a light row's padding slots
+    auto y_at = [&](int stride_idx) -> float { // y[tid + stride_idx * TPB]
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, tid * 4, stride_idx * TPB * 4, 0));
+    };
+    auto recon = [&](float a1, float a2, unsigned ww, int p) -> float {
+        const float mag = ((int)(ww >> 27) == p) ? a2 : a1;
+        return u2f(f2u(mag) | ((ww >> (WCS - 1 - p)) << 31));
+    };
+    // byte address of the S value behind row slot m for circulant position t: column base + (t + shift) mod Z
+    auto s_addr = [&](unsigned m, int t) -> int {
+        const unsigned c1 = (unsigned)t + ((m >> 8) & 2047u);
+        const unsigned c = min(c1, c1 - (unsigned)Z); // c1 - Z wraps to a huge value unless c1 >= Z
+        return (int)(((m & 255u) * (unsigned)Z + c) * 4u);
+    };
+    auto flags_collect = [&](int it) {
+        if (tid == 0) {
+            const int flag = lds_flag[0] ? 0 : 1;
+            lds_flag[0] = 0;
+            if (flag && it <= 64) hist |= (1ull << (it - 1));
+        }
+    };
+
+    float m1[J][NZ], m2[J][NZ]; // check states: R_p = +-m1, +-m2 on edge idx
+    unsigned w2[J][NZ];         // idx << 27 | output sign bits (edge p at bit WCS-1-p)
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+        for (int z = 0; z < NZ; z++) {
+            m1[j][z] = 0.0f; m2[j][z] = 0.0f; w2[j][z] = 0u; // every R starts as +0 (LDPC_Decoder.cu:82)
+        }
+
+    for (int it = 1; it < a.max_iter; it++) {
+        // The tables are loop-invariant and the compiler knows it: left alone it hoists every rotated address of every
+        // edge out of the iteration loop and spills them.  A fresh (opaque) copy of the pointer per phase keeps the
+        // loads, and the addresses computed from them, where they are used.
+        asm volatile("" : "+s"(cm));
+        // ---- phase 1: check nodes on S of iteration `it` (LDPC_Decoder.cu:279-314).  Straight-line code: a light
+        // row's padding slots (p >= MINW, meta bit 21) read some valid address and are replaced by +inf, which is
+        // neutral for min1/min2, never the first minimum, and has sign 0.
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            unsigned m[WCS];
+#pragma unroll
+            for (int p = 1; p < WCS; p++) m[p] = cm[j * WCS + p];
+            float Sv[NZ][WCS];
+#pragma unroll
+            for (int z = 0; z < NZ; z++) {
+                Sv[z][0] = S0[z];
+#pragma unroll
+                for (int p = 1; p < WCS; p++) {
+                    float sv[1];
+                    lds_ld<1>(sv, lds, s_addr(m[p], tid + z * TPB));
+                    Sv[z][p] = sv[0];
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < NZ; z++) {
+                float n1 = __builtin_inff(), n2 = __builtin_inff();
+                unsigned signs = 0;
+                int idx = 0;
+#pragma unroll
+                for (int p = 0; p < WCS; p++) {
+                    float q = Sv[z][p] - recon(m1[j][z], m2[j][z], w2[j][z], p); // Q = S - R (:206-209)
+                    if (p >= MINW) q = ((m[p] >> 21) & 1u) ? __builtin_inff() : q;
+                    const float aq = __builtin_fabsf(q);
+                    idx = (aq < n1) ? p : idx; // first edge holding the minimum (:298-305)
+                    n2 = __builtin_amdgcn_fmed3f(n1, n2, aq);
+                    n1 = __builtin_fminf(n1, aq);
+                    signs = __builtin_amdgcn_alignbit(signs, f2u(q), 31); // (signs << 1) | sign(q)
+                }
+                // R_p = Sign[25]*Sign[p] * magnitude: output sign bit p = parity of all signs XOR sign p
+                if (__builtin_popcount(signs) & 1) signs ^= (1u << WCS) - 1u;
+                m1[j][z] = n1; m2[j][z] = n2;
+                w2[j][z] = signs | ((unsigned)idx << 27);
+                // the state is complete HERE: three registers, not the chain of values it was computed from (left alone
+                // the compiler sinks the min2 chain into phase 2, where its inputs have to be spilled to survive)
+                asm volatile("" : "+v"(m1[j][z]), "+v"(m2[j][z]), "+v"(w2[j][z]));
+            }
+            __builtin_amdgcn_sched_barrier(0); // one block row's reads in flight at a time: bounds the VGPRs
+        }
+        __syncthreads();
+
+        // ---- phase 2: S of iteration it+1 = ((0 + R_0) + R_1 + ...), block rows in ascending order (:188-204) ----
+        asm volatile("" : "+s"(cm));
+        float acc0[NZ], yv[YB];
+#pragma unroll
+        for (int z = 0; z < NZ; z++) acc0[z] = 0.0f;
+        unsigned mn[WCS];
+#pragma unroll
+        for (int p = 1; p < WCS; p++) mn[p] = cm[p];
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            unsigned m[WCS];
+#pragma unroll
+            for (int p = 1; p < WCS; p++) m[p] = mn[p];
+            if (j + 1 < J) { // the next block row's slots: in flight across this one's barrier
+#pragma unroll
+                for (int p = 1; p < WCS; p++) mn[p] = cm[(j + 1) * WCS + p];
+            } else { // first batch of the closing pass
+#pragma unroll
+                for (int i = 0; i < YB; i++) yv[i] = y_at(i);
+            }
+#pragma unroll
+            for (int z = 0; z < NZ; z++) {
+                const int t = tid + z * TPB;
+                float acc[WCS];
+                int va[WCS];
+#pragma unroll
+                for (int p = 1; p < WCS; p++) {
+                    va[p] = s_addr(m[p], t);
+                    if (p >= MINW) va[p] = ((m[p] >> 21) & 1u) ? dummy : va[p];
+                    float sv[1];
+                    lds_ld<1>(sv, lds, va[p]);
+                    acc[p] = sv[0];
+                }
+                acc0[z] += recon(m1[j][z], m2[j][z], w2[j][z], 0); // column 0: this thread's own variable
+#pragma unroll
+                for (int p = 1; p < WCS; p++) {
+                    const float prev = ((m[p] >> 19) & 1u) ? 0.0f : acc[p]; // a column's first edge starts from 0
+                    const float sv[1] = {prev + recon(m1[j][z], m2[j][z], w2[j][z], p)};
+                    lds_st<1>(lds, va[p], sv);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+        // ---- ... + y closes every sum (:205): one aligned pass, channel values re-read (L2-resident).  The pass also
+        // sweeps column 0's unused words (3 % of it) rather than special-casing them.
+        int bad = 0;
+#pragma unroll
+        for (int z = 0; z < NZ; z++) {
+            S0[z] = acc0[z] + y_at(z);
+            if (HIST) bad |= (int)(tid + z * TPB < a.length) & (int)(S0[z] < 0);
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < NS; i0 += YB) {
+            float yn[YB], sv[YB][1];
+            if (i0 + YB < NS) {
+#pragma unroll
+                for (int i = 0; i < YB; i++) yn[i] = y_at(i0 + YB + i); // next batch
+            }
+#pragma unroll
+            for (int i = 0; i < YB; i++) lds_ld<1>(sv[i], lds, (tid + (i0 + i) * TPB) * 4);
+#pragma unroll
+            for (int i = 0; i < YB; i++) {
+                const int v = tid + (i0 + i) * TPB;
+                sv[i][0] += yv[i];
+                lds_st<1>(lds, v * 4, sv[i]);
+                if (HIST) bad |= (int)(v >= Z) & (int)(v < a.length) & (int)(sv[i][0] < 0);
+            }
+            if (i0 + YB < NS) {
+#pragma unroll
+                for (int i = 0; i < YB; i++) yv[i] = yn[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (HIST && bad) lds_flag[0] = 1;
+        __syncthreads();
+        if (HIST && it + 1 < a.max_iter) flags_collect(it + 1);
+    }
+}
+
+// LDS: S float[N] | flag.
+template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_qcr(QcArgs a)
+{
+    constexpr int Z = GM::Z, TPB = GM::TPB, ZR = GM::ZR, N = GM::L * Z;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
+    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (wg >= a.nWG) return;
+    const int F = a.F;
+    const int tid = threadIdx.x;
+    const int f = wg; // one frame per workgroup
+    const float *yf = a.y + (size_t)f * N;
+    // the frame's channel values as a buffer resource: loads take one VGPR offset (4 tid) plus a scalar offset, instead
+    // of a 64-bit address pair per load
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(yf), 0, N * 4, 0x00020000);
+    int *lds_flag = reinterpret_cast<int *>(lds + N * 4);
+    const bool zlast = !GM::RAGGED || (tid + (ZR - 1) * TPB < Z); // wave-uniform: this wave covers the last tile too
+
+    int bad = 0;
+    for (int v = tid; v < N; v += TPB) { // iteration 1: S = (0 + 0 + ...) + y
+        const float sv[1] = {0.0f + yf[v]};
+        lds_st<1>(lds, v * 4, sv);
+        if (HIST) bad |= (int)(v < a.length) & (int)(sv[0] < 0);
+    }
+    float S0[ZR];
+#pragma unroll
+    for (int z = 0; z < ZR; z++) S0[z] = (z < ZR - 1 || zlast) ? 0.0f + yf[tid + z * TPB] : 0.0f;
+    if (tid == 0) lds_flag[0] = 0;
+    unsigned long long hist = 0;
+    __syncthreads();
+    if (HIST) {
+        if (bad) lds_flag[0] = 1;
+        __syncthreads();
+        if (a.max_iter > 1 && tid == 0) {
+            if (!lds_flag[0]) hist |= 1ull;
+            lds_flag[0] = 0;
+        }
+    }
+
+    if (GM::RAGGED && !zlast) qcr_iterations<GM, HIST, (GM::RAGGED ? ZR - 1 : ZR)>(a, lds, lds_flag, yrs, S0, hist);
+    else qcr_iterations<GM, HIST, ZR>(a, lds, lds_flag, yrs, S0, hist);
+
+    // ---- outputs from S of iteration max_iter ----
+#pragma unroll
+    for (int z = 0; z < ZR; z++)
+        if (z < ZR - 1 || zlast) { // column 0 comes back from the registers
+            const float sv[1] = {S0[z]};
+            lds_st<1>(lds, (tid + z * TPB) * 4, sv);
+        }
+    __syncthreads();
+    bad = 0;
+    for (int n = tid; n < N; n += TPB) {
+        float sv[1];
+        lds_ld<1>(sv, lds, n * 4);
+        const bool neg = sv[0] < 0;
+        bad |= (int)(n < a.length) & (int)neg;
+        const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave (TPB % 64 == 0)
+        if ((tid & 31) == 0) a.bits[(size_t)f * (N / 32) + (n >> 5)] = (unsigned)(m >> (tid & 32));
+        if (a.app) a.app[(size_t)n * F + f] = sv[0];
+    }
+    if (bad) lds_flag[0] = 1; // (HIST: the last round has already published the same verdict)
+    __syncthreads();
+    if (tid == 0) {
+        const int flag = lds_flag[0] ? 0 : 1;
+        if (flag && a.max_iter <= 64) hist |= (1ull << (a.max_iter - 1));
+        a.D[(size_t)N * F + f] = flag;
+        if (HIST && a.hist) a.hist[f] = hist;
+    }
+}
+

@@ -149,6 +149,60 @@ def test_pon_matrix(C, orc):
     _assert_same(got, want, code.N, F)
 
 
+# the fused kernels of the second and third tier (compressed check states in LDS / in registers): one code per variant
+TIER_CODES = [("PON_LDPC.txt", 12, 69, 256, 2.6), ("J10_L60_Z160_BlockH.txt", 10, 60, 160, 3.2), ("J4_L24_Z512_BlockH.txt", 4, 24, 512, 3.6),
+              ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, 0.4)]
+
+
+@pytest.mark.parametrize("fn,J,L,Z,snr", TIER_CODES)
+def test_tier_kernels_batch_global_and_history(C, orc, fn, J, L, Z, snr):
+    """Reference early-exit rule (LDPC_Decoder.cu:150-153) and the per-iteration flag history on the compressed-state
+    and register-state kernels, ragged batch."""
+    F = 5
+    p = os.path.join(BL, fn)
+    y = _channel(orc, L * Z, F, snr)
+    ocode = orc.BinaryCode(p, J, L, Z)
+    code = C.BinaryCode.from_blockh(p, J, L, Z)
+    assert code.frames_per_wg == 1
+    want = orc.bldpc_decode(ocode, y, F, 40, early_exit=1, want_app=True)
+    got = _decode(C, code, y, F, max_iter=40, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True, want_flag_hist=True)
+    assert "compressed" in code.last_kernel or "regstate" in code.last_kernel
+    _assert_same(got, want, code.N, F)
+    mask = np.uint64((1 << want["it"]) - 1)
+    assert np.array_equal(got["flag_hist"] & mask, want["flag_hist"] & mask)
+    assert 1 < want["it"] < 40, "pick an SNR at which the batch converges before maxIT (it=%d)" % want["it"]
+    # fixed iterations with the history on: every flag of every iteration
+    want = orc.bldpc_decode(ocode, y, F, 9, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=9, exit_mode=C.EXIT_FIXED, want_app=True, want_flag_hist=True)
+    _assert_same(got, want, code.N, F)
+    assert np.array_equal(got["flag_hist"] & np.uint64(511), want["flag_hist"] & np.uint64(511))
+    for it in (1, 2):
+        want = orc.bldpc_decode(ocode, y, F, it, early_exit=0, want_app=True)
+        _assert_same(_decode(C, code, y, F, max_iter=it, exit_mode=C.EXIT_FIXED, want_app=True), want, code.N, F)
+
+
+@pytest.mark.parametrize("fn,J,L,Z,snr", TIER_CODES)
+def test_tier_kernels_special_values(C, orc, fn, J, L, Z, snr):
+    """Zeros, denormals, huge magnitudes and exact ties: the compressed states keep (min1, min2, index of the FIRST
+    minimum, signs) -- duplicated minima and zero magnitudes are where that could differ from the per-edge messages."""
+    F = 3
+    rng = np.random.default_rng(11)
+    N = L * Z
+    y = rng.standard_normal(N * F).astype(np.float32)
+    for val, cnt in ((0.0, N // 8), (-0.0, N // 8), (1e-41, N // 16), (-3e-42, N // 16), (3e38, N // 64), (-3e38, N // 64), (0.5, N // 2),
+                     (-0.5, N // 2)):
+        y[rng.integers(0, N * F, cnt)] = val
+    p = os.path.join(BL, fn)
+    ocode = orc.BinaryCode(p, J, L, Z)
+    code = C.BinaryCode.from_blockh(p, J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 6, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=6, exit_mode=C.EXIT_FIXED, want_app=True)
+    assert "compressed" in code.last_kernel or "regstate" in code.last_kernel
+    _assert_same(got, want, code.N, F)
+    got = _decode(C, code, y, F, max_iter=6, exit_mode=C.EXIT_FIXED, kernel=C.KERNEL_TABLE, want_app=True)
+    _assert_same(got, want, code.N, F)
+
+
 def test_special_values(C, orc):
     """Zeros, denormals, huge magnitudes, exact ties (duplicate minima) -- still bitwise equal."""
     J, L, Z, F = 4, 24, 96, 8
