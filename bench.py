@@ -69,7 +69,9 @@ def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
     os.environ["OMP_NUM_THREADS"] = str(cores)
     code = orc.BinaryCode(os.path.join(ROOT, "data", "bldpc", name), J, L, Z)
     if nframes <= 0:
-        nframes = 1536 * cores // 16 * 16  # ~115 cw/s/core at 50 iterations -> on the order of 10-20 s of CPU work
+        # ~115 codewords/s/core for J4_L24_Z96 (E = 7680 edges) at 50 iterations, inversely proportional to the edge
+        # count and the iterations: size the sample for ~13 s of CPU work
+        nframes = max(16, int(13.0 * 115.0 * cores * (7680.0 / (int((code.H != -1).sum()) * Z)) * (50.0 / max(iters, 1))) // 16 * 16)
     reps = (nframes + y_block.shape[1] - 1) // y_block.shape[1]
     y = np.ascontiguousarray(np.tile(y_block, (1, reps))[:, :nframes]).reshape(-1)
     orc.bldpc_decode(code, y, nframes, 1, early_exit=0)  # touch pages / spin up the OpenMP threads

@@ -23,7 +23,12 @@ def one(pattern):
     return g[-1] if g else None
 
 
+def _db(d):
+    return one(os.path.join(d, "**", "*_results.db"))
+
+
 def counters(d, match):
+    """Average per launch of every counter of the kernels matching `match` (csv output, or rocprofv3's sqlite database)."""
     p = one(os.path.join(d, "**", "*counter_collection.csv"))
     agg = collections.defaultdict(list)
     kname = None
@@ -32,7 +37,37 @@ def counters(d, match):
             if match in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 kname = r["Kernel_Name"]
+    elif _db(d):
+        import sqlite3
+        cur = sqlite3.connect(_db(d)).cursor()
+        # one row per (dispatch, counter, hardware instance): sum the instances of a dispatch, average the dispatches
+        per = collections.defaultdict(float)
+        for kn, cn, disp, val in cur.execute("select kernel_name, counter_name, dispatch_id, value from counters_collection"):
+            if match in kn:
+                per[(cn, disp)] += float(val)
+                kname = kn
+        for (cn, _), v in per.items():
+            agg[cn].append(v)
     return {k: sum(v) / len(v) for k, v in agg.items()}, kname
+
+
+def kernel_stats(trace, dst):
+    """Copy (csv) or rebuild (sqlite) the --kernel-trace --stats table; returns its rows."""
+    st = one(os.path.join(trace, "**", "*kernel_stats.csv"))
+    if st:
+        shutil.copy(st, dst)
+    else:
+        import sqlite3
+        cur = sqlite3.connect(_db(trace)).cursor()
+        rows = list(cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels "
+                                "group by name order by 3 desc"))
+        tot = sum(r[2] for r in rows) or 1
+        with open(dst, "w", newline="") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100.0 * r[2] / tot, 2), r[4], r[5]])
+    return list(csv.DictReader(open(dst)))
 
 
 def main():
@@ -40,9 +75,7 @@ def main():
     sq = sys.argv[6] if len(sys.argv) > 6 else None
     match = sys.argv[7] if len(sys.argv) > 7 else "k_qc"
     here = os.path.dirname(os.path.abspath(__file__))
-    st = one(os.path.join(trace, "**", "*kernel_stats.csv"))
-    shutil.copy(st, os.path.join(here, "%s_%s_kernel_stats.csv" % (tag, name)))
-    rows = [r for r in csv.DictReader(open(st)) if match in r["Name"]]
+    rows = [r for r in kernel_stats(trace, os.path.join(here, "%s_%s_kernel_stats.csv" % (tag, name))) if match in r["Name"]]
     dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     f, kn = counters(fetch, match)
     w, _ = counters(write, match)
