@@ -121,9 +121,9 @@ static int up(void **dst, const void *src, size_t bytes)
 using NbKernel = void (*)(NbArgs);
 static NbKernel nb_kernel(int q, int dv)
 {
-    if (q == 64) return dv <= 2 ? k_nb_ems<64, 2> : k_nb_ems<64, kNbMaxDv>;
-    if (q == 32) return dv <= 2 ? k_nb_ems<32, 2> : k_nb_ems<32, kNbMaxDv>;
-    return dv <= 2 ? k_nb_ems<16, 2> : k_nb_ems<16, kNbMaxDv>;
+    if (q == 64) return dv <= 2 ? k_nb_ems<64, 2, nb_threads(64)> : k_nb_ems<64, kNbMaxDv, nb_threads(64)>;
+    if (q == 32) return dv <= 2 ? k_nb_ems<32, 2, nb_threads(32)> : k_nb_ems<32, kNbMaxDv, nb_threads(32)>;
+    return dv <= 2 ? k_nb_ems<16, 2, nb_threads(16)> : k_nb_ems<16, kNbMaxDv, nb_threads(16)>;
 }
 
 static size_t nb_lds_bytes(int N, int M, int q, int dv, int dc)
@@ -141,7 +141,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     if (N <= 0 || M <= 0 || q < 4 || (1 << m) != q) return fail(NBLDPC_EINVAL, "bad dimensions N=%d M=%d q=%d", N, M, q);
     if (q != 16 && q != 32 && q != 64) return fail(NBLDPC_EUNSUPPORTED, "fused EMS kernel supports q in {16,32,64} (got %d)", q);
     if (dv > kNbMaxDv || dc > kNbMaxW) return fail(NBLDPC_EUNSUPPORTED, "dvmax=%d (<= %d) / dcmax=%d (<= %d) unsupported", dv, kNbMaxDv, dc, kNbMaxW);
-    if (M * dc > kNbThreads || M > kNbThreads) return fail(NBLDPC_EUNSUPPORTED, "M*dcmax = %d exceeds %d check-edge threads per frame", M * dc, kNbThreads);
+    if (M * dc > nb_threads(q) || M > nb_threads(q)) return fail(NBLDPC_EUNSUPPORTED, "M*dcmax = %d exceeds %d check-edge threads per frame", M * dc, nb_threads(q));
     const size_t lds = nb_lds_bytes(N, M, q, dv, dc);
     if (lds > 160 * 1024) return fail(NBLDPC_EUNSUPPORTED, "per-frame message state %zu B exceeds the 160 KiB LDS of one CU", lds);
     // cross indices: index_in_CN / index_in_VN (LDPC_Decoder.cpp:106-130), first match
@@ -220,7 +220,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     a.N = c->N; a.M = c->M; a.q = c->q; a.dv = c->dv; a.dc = c->dc; a.B = B; a.Nm = Nm; a.Nc = Nc; a.max_iter = maxIT;
     a.dcmax_cfg = maxdc_cfg > 0 ? maxdc_cfg : c->dc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(kNbThreads), c->lds_bytes, st, a);
+    hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }

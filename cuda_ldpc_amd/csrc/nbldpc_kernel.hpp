@@ -27,6 +27,7 @@
 namespace cldpc {
 
 constexpr int kNbThreads = 1024;
+__host__ __device__ constexpr int nb_threads(int q) { return 1024; } // the phases are latency chains per wave: more waves, shorter chains
 constexpr int kNbMaxDv = 8;
 constexpr int kNbMaxW = 6; // row weights handled by the templated walk
 
@@ -50,11 +51,22 @@ struct NbArgs {
 
 __host__ __device__ inline int nb_pair_stride(int q) { return 2 * q + 2; } // floats per edge (+2: bank skew)
 
+// Maximum over the 64 lanes, in every lane: DPP butterflies inside each row of 16 (no LDS round trips -- six
+// dependent ds_bpermute cost ~1 us per variable node), two row broadcasts, one v_readlane.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float nb_dpp_max(float v)
+{
+    const int x = __builtin_bit_cast(int, v);
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false)));
+}
 __device__ __forceinline__ float nb_wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = nb_dpp_max<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v = nb_dpp_max<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
+    v = nb_dpp_max<0x141, 0xf>(v); // row_half_mirror
+    v = nb_dpp_max<0x140, 0xf>(v); // row_mirror: every lane of a row holds the row's maximum
+    v = nb_dpp_max<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v = nb_dpp_max<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 
@@ -139,6 +151,9 @@ template <int D, int NACT> __device__ __forceinline__ void nb_t1(NbCn<NACT> &c, 
 // conf(q, 1) entered with diff == 0 at depth D (LDPC_Decoder.cpp:286 via :319-359).
 // CH = leaves batched per LDS round trip (their symbols are pairwise distinct inside one k-loop,
 // because the sorted symbol list is a permutation and multiplication by h != 0 is a bijection).
+// The float chain through c.s is the critical path of the whole phase (one rounding step after another, as the
+// reference's by-reference recursion dictates); everything else is kept off it: the next batch's pairs and this
+// batch's E entries (their addresses are pure symbol arithmetic) are requested BEFORE the chain runs.
 template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NACT> &c, int symbase)
 {
     if constexpr (D == NACT - 1) {
@@ -165,27 +180,31 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
         c.s = c.s + c.v0[D];
         nb_t0<D + 1, NACT, Q>(c, symbase ^ c.m0[D]);
         c.s = c.s - c.v0[D];
+        int sfx = symbase; // symbol of a leaf that deviates here: every deeper position at k = 0
+#pragma unroll
+        for (int d = D + 1; d < NACT; d++) sfx ^= c.m0[d];
         constexpr int CH = ((Q - 1) % 7 == 0) ? 7 : 1;
         for (int k0 = 1; k0 < Q; k0 += CH) {
             float v[CH], sl[CH], ev[CH];
-            int m[CH], sy[CH];
+            int sy[CH];
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 const float2 pr = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (k0 + i));
                 v[i] = pr.x;
-                m[i] = __float_as_int(pr.y);
+                sy[i] = (sfx ^ __float_as_int(pr.y)) * c.TC;
             }
 #pragma unroll
+            for (int i = 0; i < CH; i++) ev[i] = c.E[sy[i]];
+#pragma unroll
             for (int i = 0; i < CH; i++) {
+                int unused;
                 c.s = c.s + v[i];
-                nb_t1<D + 1, NACT>(c, symbase ^ m[i], sl[i], sy[i]);
+                nb_t1<D + 1, NACT>(c, 0, sl[i], unused);
                 c.s = c.s - v[i];
             }
 #pragma unroll
-            for (int i = 0; i < CH; i++) ev[i] = c.E[sy[i] * c.TC];
-#pragma unroll
             for (int i = 0; i < CH; i++)
-                if (sl[i] > ev[i]) c.E[sy[i] * c.TC] = sl[i]; // :322-325
+                if (sl[i] > ev[i]) c.E[sy[i]] = sl[i]; // :322-325
         }
     }
 }
@@ -244,13 +263,14 @@ __device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, cons
 }
 
 // Q: field size (= lanes used per vector); DVM: bound on the column weight (loops over a node's edges are unrolled to it)
-template <int Q, int DVM> __global__ __launch_bounds__(kNbThreads) void k_nb_ems(NbArgs a)
+template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems(NbArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int frame = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = kNbThreads / 64;
-    const int N = a.N, M = a.M, q = a.q, dv = a.dv, dc = a.dc;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = NT / 64;
+    constexpr int q = Q; // == a.q (the host picks the instantiation)
+    const int N = a.N, M = a.M, dv = a.dv, dc = a.dc;
     const int NE = N * dv, TC = M * dc, PST = nb_pair_stride(q);
     const int TCP = TC + 1; // E row stride: odd, so a variable node reading one thread's column across symbols spreads over the banks
     float *pairs = lds;                    // [NE][PST]
@@ -267,15 +287,15 @@ template <int Q, int DVM> __global__ __launch_bounds__(kNbThreads) void k_nb_ems
     unsigned short *t_cn_src = t_cn_w + M;      // [M][dc]
     unsigned short *t_cn_gf = t_cn_src + TC;    // [M][dc]
     unsigned short *t_cn_vn = t_cn_gf + TC;     // [M][dc]
-    for (int i = tid; i < N; i += kNbThreads) t_vn_w[i] = (unsigned short)a.vn_w[i];
-    for (int i = tid; i < NE; i += kNbThreads) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
-    for (int i = tid; i < M; i += kNbThreads) t_cn_w[i] = (unsigned short)a.cn_w[i];
-    for (int i = tid; i < TC; i += kNbThreads) {
+    for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
+    for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
+    for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
+    for (int i = tid; i < TC; i += NT) {
         t_cn_src[i] = (unsigned short)a.cn_src[i]; t_cn_gf[i] = (unsigned short)a.cn_gf[i]; t_cn_vn[i] = (unsigned short)a.cn_vn[i];
     }
 
-    for (int i = tid; i < q * q; i += kNbThreads) mulb[i] = a.mul[i];
-    for (int i = tid; i < q * TCP; i += kNbThreads) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+    for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
+    for (int i = tid; i < q * TCP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
     if (tid == 0) flag[0] = 0;
     __syncthreads();
 
@@ -283,37 +303,57 @@ template <int Q, int DVM> __global__ __launch_bounds__(kNbThreads) void k_nb_ems
     float *LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
     const bool active = lane < q - 1;          // lanes 0..q-2 <-> field elements 1..q-1
     const int sym = active ? lane + 1 : 0;     // lane q-1 carries element 0 (value 0, :250)
-    int it = 0, ok = 0;
-    while (it < a.max_iter) {
-        it++;
-        // ---- A: variable nodes ------------------------------------------------------------
-        for (int col = wave; col < N; col += nwaves) {
-            const int w = t_vn_w[col];
-            float llr = active ? Lch[col * (q - 1) + lane] : 0.0f;
-            float c2[DVM];
+    constexpr int CPW = 96 * 64 / NT; // columns per wave whose channel vector stays in registers (N <= 96)
+    float lch[CPW];
 #pragma unroll
-            for (int d = 0; d < DVM; d++) {
-                c2[d] = 0.0f;
-                if (d < w) {
-                    const int thr = t_vn_thr[col * dv + d], h = t_vn_gf[col * dv + d];
-                    const float e0 = E[thr];
-                    const float ev = E[mulb[sym * q + h] * TCP + thr];
-                    if (!(NB_ABLATE & 4)) c2[d] = (float)((double)(ev - e0) / 1.2); // :309, double division
-                    else c2[d] = (ev - e0) * 0.83f;
-                    llr = llr + c2[d];                         // :208-213, ascending d
-                }
-            }
-            // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
-            const float v = active ? llr : -__builtin_inff();
-            const float mx = nb_wave_max(v);
-            const unsigned long long eq = __ballot(active && v == mx);
-            const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
+    for (int ci = 0; ci < CPW; ci++) {
+        const int col = min(wave + ci * nwaves, N - 1);
+        lch[ci] = active ? Lch[col * (q - 1) + lane] : 0.0f;
+    }
+    // one variable node, lane <-> field element (LDPC_Decoder.cpp:202-251)
+    auto vn_column = [&](int col, float llr, bool store) {
+        const int w = t_vn_w[col];
+        float c2[DVM];
+#pragma unroll
+        for (int d = 0; d < DVM; d++) {
+            const int dd = min(d, dv - 1);
+            const int thr = t_vn_thr[col * dv + dd], h = t_vn_gf[col * dv + dd];
+            const float e0 = E[thr];
+            const float ev = E[mulb[sym * q + h] * TCP + thr];
+            float c;
+            if (!(NB_ABLATE & 4)) c = (float)((double)(ev - e0) / 1.2); // :309, double division
+            else c = (ev - e0) * 0.83f;
+            c2[d] = (d < w) ? c : 0.0f;
+            llr = (d < w) ? llr + c : llr;             // :208-213, ascending d
+        }
+        // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
+        const float v = active ? llr : -__builtin_inff();
+        const float mx = nb_wave_max(v);
+        const unsigned long long eq = __ballot(active && v == mx);
+        const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
+        if (store) {
             if (lane == 0) outs[col] = dec;
             if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
 #pragma unroll
             for (int d = 0; d < DVM; d++)
                 if (d < w && lane < q) pairs[(col * dv + d) * PST + 2 * lane] = active ? llr - c2[d] : 0.0f; // :241-251
         }
+    };
+    int it = 0, ok = 0;
+    while (it < a.max_iter) {
+        it++;
+        // ---- A: variable nodes ------------------------------------------------------------
+        // The first CPW columns of a wave run as straight-line code on a clamped column index (only the stores are
+        // conditional), so that their table look-ups, E gathers and double divisions overlap; L_ch stays in registers.
+        int wv = wave; // opaque per iteration: otherwise every column's addresses are hoisted out of the loop and spilled
+        asm volatile("" : "+s"(wv));
+#pragma unroll
+        for (int ci = 0; ci < CPW; ci++) {
+            const int col = wv + ci * nwaves;
+            vn_column(min(col, N - 1), lch[ci], col < N);
+            __builtin_amdgcn_sched_barrier(0); // bounds the registers (1024 threads: 128 VGPRs)
+        }
+        for (int col = wave + CPW * nwaves; col < N; col += nwaves) vn_column(col, active ? Lch[col * (q - 1) + lane] : 0.0f, true);
         __syncthreads();
         // ---- S: syndrome (:218-238) ----------------------------------------------------------
         if (tid < M) {
@@ -375,7 +415,7 @@ template <int Q, int DVM> __global__ __launch_bounds__(kNbThreads) void k_nb_ems
         if (tid == 0) flag[0] = 0; // next write is two barriers away, last read was two barriers ago
     }
     // ---- outputs ------------------------------------------------------------------------------
-    for (int i = tid; i < N; i += kNbThreads) a.out[(size_t)frame * N + i] = outs[i];
+    for (int i = tid; i < N; i += NT) a.out[(size_t)frame * N + i] = outs[i];
     if (tid == 0) {
         a.iters[frame] = it;
         a.ok[frame] = ok;
