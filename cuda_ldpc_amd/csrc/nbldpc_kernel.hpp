@@ -53,6 +53,21 @@ __host__ __device__ inline int nb_pair_stride(int q) { return 2 * q + 2; } // fl
 
 // Maximum over the 64 lanes, in every lane: DPP butterflies inside each row of 16 (no LDS round trips -- six
 // dependent ds_bpermute cost ~1 us per variable node), two row broadcasts, one v_readlane.
+// (float)((double)x / 1.2) of LDPC_Decoder.cpp:309 without the ~15-instruction f64 division: with r = RN(1/1.2),
+// q0 = x*r, e = fma(-1.2, q0, x) (exact residual), q1 = fma(e, r, q0) is the correctly rounded double quotient
+// (Markstein's correction step); tests/c/div12_exhaustive.c checks the float result for every finite non-zero float.
+// Zeros and infinities divide to themselves.
+__device__ __forceinline__ float nb_div12(float x)
+{
+    constexpr double r = 1.0 / 1.2;
+    const double xd = (double)x;
+    const double q0 = xd * r;
+    const double e = __builtin_fma(-1.2, q0, xd);
+    const float q = (float)__builtin_fma(e, r, q0);
+    if (NB_ABLATE & 32) return (float)((double)x / 1.2);
+    return (x == 0.0f || __builtin_isinf(x)) ? x : q;
+}
+
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float nb_dpp_max(float v)
 {
     const int x = __builtin_bit_cast(int, v);
@@ -71,9 +86,9 @@ __device__ __forceinline__ float nb_wave_max(float v)
 
 
 // 64-lane bitonic sort, descending, of the pairwise-distinct 64-bit keys (hi, lo).  One compare-exchange step:
-// the partner lane's key arrives through the LDS crossbar (ds_swizzle / ds_bpermute, no VALU), the compare is
-// a 64-bit subtract-with-borrow chain on VCC, the keep-max lane pattern of the step is a compile-time constant
-// XNORed into VCC on the scalar unit.
+// the partner lane's key arrives through DPP (partners 1, 2, 8 lanes away: 14 of the 21 steps) or the LDS crossbar
+// (ds_swizzle / ds_bpermute: 4, 16, 32 lanes away), the compare is a 64-bit subtract-with-borrow chain on VCC, the
+// keep-max lane pattern of the step is a compile-time constant XORed into VCC on the scalar unit.
 __host__ __device__ constexpr unsigned long long nb_keepmax_mask(int K, int J)
 {
     unsigned long long m = 0;
@@ -85,21 +100,45 @@ __host__ __device__ constexpr unsigned long long nb_keepmax_mask(int K, int J)
 }
 template <int K, int J> __device__ __forceinline__ void nb_bitonic_step(uint32_t &hi, uint32_t &lo)
 {
-    uint32_t phi, plo, t;
-    if constexpr (J < 32) {
-        phi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)hi, (J << 10) | 0x1f);
-        plo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)lo, (J << 10) | 0x1f);
-    } else {
-        phi = (uint32_t)__shfl_xor((int)hi, 32, 64);
-        plo = (uint32_t)__shfl_xor((int)lo, 32, 64);
-    }
     constexpr unsigned long long KM = nb_keepmax_mask(K, J);
-    // vcc = (partner > mine); take the partner's key where that equals "this lane keeps the larger one"
-    asm volatile("v_sub_co_u32 %2, vcc, %1, %4\n\tv_subb_co_u32 %2, vcc, %0, %3, vcc\n\ts_xnor_b64 vcc, vcc, %5\n\t"
-                 "v_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc"
-                 : "+v"(hi), "+v"(lo), "=&v"(t)
-                 : "v"(phi), "v"(plo), "s"(KM)
-                 : "vcc");
+    if constexpr ((J == 1 || J == 2 || J == 8) && !(NB_ABLATE & 16)) {
+        // The partner lane (lane ^ J) is inside the lane's own row of 16: it is read through DPP as an operand of the
+        // compare and of the selects themselves -- no data movement instruction, no LDS crossbar.
+        //   vcc  = borrow of the 64-bit subtract-with-borrow chain over (mine, partner)
+        //   vcc  = ~(vcc ^ KM);   key = vcc ? mine : partner
+        // The polarity of this sequence is pinned by tests/cpp/dpp_step_test.hip (test_nbldpc_gpu.py), which checks every
+        // (K, J) step of the network against a plain 64-bit compare on the GPU.
+        uint32_t t;
+#define NB_DPP_STEP(CTRL)                                                                                         \
+        asm volatile("s_nop 1\n\t" /* a VALU write of %0 / %1 right before (the compiler's own code) -> DPP read: 2 wait states */ \
+                     "v_subrev_co_u32_dpp %2, vcc, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                  \
+                     "v_subbrev_co_u32_dpp %2, vcc, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"            \
+                     "s_xnor_b64 vcc, vcc, %3\n\t"                                                                \
+                     "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                    \
+                     "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                        \
+                     : "+v"(hi), "+v"(lo), "=&v"(t)                                                                \
+                     : "s"(KM)                                                                                     \
+                     : "vcc")
+        if constexpr (J == 1) NB_DPP_STEP("quad_perm:[1,0,3,2]");
+        else if constexpr (J == 2) NB_DPP_STEP("quad_perm:[2,3,0,1]");
+        else NB_DPP_STEP("row_ror:8");
+#undef NB_DPP_STEP
+    } else {
+        uint32_t phi, plo, t;
+        if constexpr (J < 32) {
+            phi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)hi, (J << 10) | 0x1f);
+            plo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)lo, (J << 10) | 0x1f);
+        } else {
+            phi = (uint32_t)__shfl_xor((int)hi, 32, 64);
+            plo = (uint32_t)__shfl_xor((int)lo, 32, 64);
+        }
+        // vcc = (partner > mine); take the partner's key where that equals "this lane keeps the larger one"
+        asm volatile("v_sub_co_u32 %2, vcc, %1, %4\n\tv_subb_co_u32 %2, vcc, %0, %3, vcc\n\ts_xnor_b64 vcc, vcc, %5\n\t"
+                     "v_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc"
+                     : "+v"(hi), "+v"(lo), "=&v"(t)
+                     : "v"(phi), "v"(plo), "s"(KM)
+                     : "vcc");
+    }
 }
 // W independent sorts advance through the network together: each step waits ~an LDS round trip for its
 // partner keys, so one sort alone is latency-bound; W of them fill that latency with each other's work.
@@ -172,7 +211,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 c.s = c.s + v[i];
-                c.E[(symbase ^ m[i]) * c.TC] = c.s;
+                c.E[__mul24(symbase ^ m[i], c.TC)] = c.s;
                 c.s = c.s - v[i];
             }
         }
@@ -191,7 +230,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
             for (int i = 0; i < CH; i++) {
                 const float2 pr = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (k0 + i));
                 v[i] = pr.x;
-                sy[i] = (sfx ^ __float_as_int(pr.y)) * c.TC;
+                sy[i] = __mul24(sfx ^ __float_as_int(pr.y), c.TC); // v_mul_u32_u24: full rate (v_mul_lo_u32 is not)
             }
 #pragma unroll
             for (int i = 0; i < CH; i++) ev[i] = c.E[sy[i]];
@@ -203,8 +242,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
                 c.s = c.s - v[i];
             }
 #pragma unroll
-            for (int i = 0; i < CH; i++)
-                if (sl[i] > ev[i]) c.E[sy[i]] = sl[i]; // :322-325
+            for (int i = 0; i < CH; i++) c.E[sy[i]] = (sl[i] > ev[i]) ? sl[i] : ev[i]; // :322-325, as a select: no exec juggling
         }
     }
 }
@@ -321,8 +359,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
             const float e0 = E[thr];
             const float ev = E[mulb[sym * q + h] * TCP + thr];
             float c;
-            if (!(NB_ABLATE & 4)) c = (float)((double)(ev - e0) / 1.2); // :309, double division
-            else c = (ev - e0) * 0.83f;
+            c = nb_div12(ev - e0); // :309, double division
             c2[d] = (d < w) ? c : 0.0f;
             llr = (d < w) ? llr + c : llr;             // :208-213, ascending d
         }
@@ -426,7 +463,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         if (e < t_cn_w[row]) {
             const int h = t_cn_gf[tid];
             const float e0 = E[tid];
-            for (int k = 1; k < q; k++) o[k - 1] = (float)((double)(E[mulb[k * q + h] * TCP + tid] - e0) / 1.2);
+            for (int k = 1; k < q; k++) o[k - 1] = nb_div12(E[mulb[k * q + h] * TCP + tid] - e0);
         } else {
             for (int k = 1; k < q; k++) o[k - 1] = 0.0f;
         }

@@ -181,3 +181,19 @@ def test_nb_simulation_counts_match_reference_style_loop(nb, code, ocode, orc):
     assert (SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration) == (frames, errf, errb, its)
     assert np.array_equal(seed, oseed)
 
+
+
+def test_bitonic_steps(tmp_path):
+    """Every compare-exchange step (K, J) of the kernel's 64-lane bitonic network -- DPP-fused for partners 1, 2 and 8
+    lanes away, LDS crossbar for the rest -- against a plain 64-bit compare, on duplicated and distinct keys."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dpp_step_test")
+    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function",
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "dpp_step_test.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "total 0" in out.stdout, out.stdout + out.stderr
