@@ -67,6 +67,7 @@ struct QcArgs {
     const unsigned *cn_meta;    // [J][WCS] padded row slots
     const unsigned *vn_meta;    // [L][WVS] column edges, top -> bottom
     int J, L, WVS;
+    int lc;                     // register-state kernel (k_qcr): the block column kept in registers
 };
 
 template <int NF> struct Msg;
@@ -825,6 +826,9 @@ inline const QcVariant *qc_variants(int *count)
         X2(2, 12, 24, 96, 8, 6, 4, 3) /* J12_L24_Z96 (rows padded 7 -> 8): 768 thr, 92 KB                        */
         X2(2, 6, 24, 96, 16, 4, 3, 3) /* J6_L24_Z96 (rows padded 15 -> 16): 576 thr, 92 KB                       */
         QC_VARIANTS(X)
+        /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp), several workgroups per CU */
+        XR(12, 69, 256, 256, 23, 22, 3) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22): 69 KB, 2 WG/CU */
+        XR(4, 24, 512, 512, 20, 20, 8)  /* J4_L24_Z512: 48 KB, 3 WG/CU                                                      */
         /* compressed check state (bldpc_qcc_kernel.hpp): any J, L with ceil(L/G) <= CPT and row weight <= WCS */
         XC(256, 256, 4, 18, 24) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22)       */
         XC(160, 192, 5, 12, 24) /* the Z = 160 family, J10 ... J48, L60                                   */
@@ -851,7 +855,7 @@ struct QcPlan {
     QcVnEdge *d_vn = nullptr;
     unsigned char *d_wv = nullptr;
     unsigned *d_cn_meta = nullptr, *d_vn_meta = nullptr; // compressed-state kernel
-    int WVS = 0, lds_bytes = 0;
+    int WVS = 0, lds_bytes = 0, lc = 0;
     char name[96] = "qc_lds(unavailable)";
 };
 
@@ -915,21 +919,29 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     }
     if (q->variant < 0) return BLDPC_OK;
     const QcVariant &v = vars[q->variant];
-    if (v.regstate) { // row slots with first-edge-of-column marks; block rows rotated until column 0 has shift 0
+    if (v.regstate) { // row slots with first-edge-of-column marks
+        // the register-resident column LC: one that meets every block row (prefer the heaviest traffic saved = any such);
+        // every block row is rotated until its LC block has shift 0, and lists that block first
+        int lc = -1;
+        for (int l = 0; l < L && lc < 0; l++)
+            if (wv[l] == J) lc = l;
+        bool ok = lc >= 0;
+        for (int l = 0; l < L; l++) ok = ok && wv[l] > 0; // an unconnected column would keep a stale S
+        if (!ok) { q->variant = -1; return BLDPC_OK; }
         std::vector<unsigned> cm((size_t)J * v.WC, qcr_cn_meta(0, 0, 0, 1));
         std::vector<int> seen(L, 0);
-        bool ok = true;
-        for (int j = 0; j < J && ok; j++) {
-            ok = rowptr[j + 1] > rowptr[j] && cn[rowptr[j]].col == 0; // column 0 must meet every block row (slot 0)
-            const int rot = ok ? cn[rowptr[j]].shift : 0;
+        for (int j = 0; j < J; j++) {
+            int rot = 0;
+            for (int e = rowptr[j]; e < rowptr[j + 1]; e++)
+                if (cn[e].col == lc) rot = cn[e].shift;
+            int pos = 1;
             for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
                 const int l = cn[e].col;
                 seen[l]++;
-                cm[(size_t)j * v.WC + (e - rowptr[j])] = qcr_cn_meta(l, (cn[e].shift - rot + Z) % Z, seen[l] == 1, 0);
+                cm[(size_t)j * v.WC + (l == lc ? 0 : pos++)] = qcr_cn_meta(l, (cn[e].shift - rot + Z) % Z, seen[l] == 1, 0);
             }
         }
-        for (int l = 0; l < L; l++) ok = ok && wv[l] > 0; // an unconnected column would keep a stale S
-        if (!ok) { q->variant = -1; return BLDPC_OK; }
+        q->lc = lc;
         CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
     }
@@ -1000,7 +1012,7 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     a.F = F;
     a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
     a.max_iter = max_iter; a.length = length;
-    a.cn_meta = q->d_cn_meta; a.vn_meta = q->d_vn_meta; a.J = q->J; a.L = q->L; a.WVS = q->WVS;
+    a.cn_meta = q->d_cn_meta; a.vn_meta = q->d_vn_meta; a.J = q->J; a.L = q->L; a.WVS = q->WVS; a.lc = q->lc;
     const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
     if (ev0) (void)hipEventRecord(ev0, st);
     hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);

@@ -21,10 +21,13 @@
 //           variable is met by at most one edge, so `S[v] = S[v] + R` is race-free and happens in exactly the
 //           reference's order.  A column's first edge stores 0 + R (overwriting the old S, which phase 1 no
 //           longer needs); one aligned pass adds the channel values at the end.
-// Column 0 stays out of LDS altogether.  The order of the check rows INSIDE a block row is immaterial (checks
-// have no outputs), so the host rotates every block row until its column-0 block has shift 0 (all other shifts of
-// the row move with it); then variable (0, t) meets check (j, t) in every block row j, i.e. only checks owned by
-// the thread that also owns position t: its S and its running sum are registers.
+// One block column stays out of LDS altogether: a column LC that meets every block row (the host picks one; codes
+// without one do not use this kernel).  The order of the check rows INSIDE a block row is immaterial (checks have no
+// outputs), so the host rotates every block row until its LC block has shift 0 (all other shifts of the row move
+// with it); then variable (LC, t) meets check (j, t) in every block row j, i.e. only checks owned by the thread that
+// also owns position t: its S and its running sum are registers.  The host also lists that block first in every
+// row: the order of a row's slots does not matter either (min1, min2 and the sign product are symmetric, and when the
+// minimum is duplicated min1 == min2, so the "first index" of LDPC_Decoder.cu:298-305 selects among equal values).
 // The per-edge tables (column, shift, first-edge mark) are wave-uniform scalar loads, fetched one block row ahead.
 // When TPB does not divide Z the last tile of the circulant is covered by the first waves only; those waves run
 // an instantiation of the iteration loop with one more tile than the others (same number of barriers in both).
@@ -36,7 +39,7 @@ template <int J_, int L_, int Z_, int TPB_, int WCS_, int MINW_, int YB_> struct
     static constexpr bool RAGGED = (Z % TPB) != 0;
     static_assert((L * Z) % (TPB * YB) == 0, "the closing pass runs in whole batches");
     static_assert(Z % 64 == 0 && TPB % 64 == 0 && TPB <= 1024, "threads must tile the circulant in whole waves");
-    static_assert(WCS <= 27 && MINW >= 2, "sign bits and the 5-bit index share one word; slot 0 is column 0");
+    static_assert(WCS <= 27 && MINW >= 2, "sign bits and the 5-bit index share one word; slot 0 is the register-resident column");
 };
 
 // CN slot word: column | shift << 8 | first edge of its column << 19 | padding slot << 21
@@ -48,7 +51,7 @@ __host__ __device__ inline unsigned qcr_cn_meta(int col, int shift, int first, i
 typedef __attribute__((address_space(4))) const unsigned qcr_const_u32;
 
 // Iterations 1 .. max_iter-1 for a wave that covers NZ tiles of the circulant.  S0[z]: a-posteriori value of
-// variable (0, tid + z*TPB), kept in registers across the whole decode.
+// variable (LC, tid + z*TPB), kept in registers across the whole decode.
 template <typename GM, bool HIST, int NZ>
 __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *lds_flag, const __amdgpu_buffer_rsrc_t yrs,
                                                float (&S0)[GM::ZR], unsigned long long &hist)
@@ -58,9 +61,13 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
     // row slots, wave-uniform; read through the constant address space so that they are scalar loads whatever the
     // compiler can or can not prove about the kernel's own stores
     const qcr_const_u32 *cm = (const qcr_const_u32 *)a.cn_meta;
-    const int dummy = tid * 4; // column 0's (unused) LDS words take the writes of a light row's padding slots
+    const int lcbase = a.lc * Z; // first variable of the register-resident column
+    const int dummy = (lcbase + tid) * 4; // that column's (unused) LDS words take the writes of a light row's padding slots
     auto y_at = [&](int stride_idx) -> float { // y[tid + stride_idx * TPB]
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, tid * 4, stride_idx * TPB * 4, 0));
+    };
+    auto y_lc = [&](int z) -> float { // y[LC*Z + tid + z * TPB]
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, tid * 4, (lcbase + z * TPB) * 4, 0));
     };
     auto recon = [&](float a1, float a2, unsigned ww, int p) -> float {
         const float mag = ((int)(ww >> 27) == p) ? a2 : a1;
@@ -173,7 +180,7 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
                     lds_ld<1>(sv, lds, va[p]);
                     acc[p] = sv[0];
                 }
-                acc0[z] += recon(m1[j][z], m2[j][z], w2[j][z], 0); // column 0: this thread's own variable
+                acc0[z] += recon(m1[j][z], m2[j][z], w2[j][z], 0); // slot 0 = column LC: this thread's own variable
 #pragma unroll
                 for (int p = 1; p < WCS; p++) {
                     const float prev = ((m[p] >> 19) & 1u) ? 0.0f : acc[p]; // a column's first edge starts from 0
@@ -185,12 +192,12 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
             __syncthreads();
         }
         // ---- ... + y closes every sum (:205): one aligned pass, channel values re-read (L2-resident).  The pass also
-        // sweeps column 0's unused words (3 % of it) rather than special-casing them.
+        // sweeps column LC's unused words (1/L of it) rather than special-casing them.
         int bad = 0;
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
-            S0[z] = acc0[z] + y_at(z);
-            if (HIST) bad |= (int)(tid + z * TPB < a.length) & (int)(S0[z] < 0);
+            S0[z] = acc0[z] + y_lc(z);
+            if (HIST) bad |= (int)(lcbase + tid + z * TPB < a.length) & (int)(S0[z] < 0);
         }
 #pragma unroll
         for (int i0 = 0; i0 < NS; i0 += YB) {
@@ -206,7 +213,7 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
                 const int v = tid + (i0 + i) * TPB;
                 sv[i][0] += yv[i];
                 lds_st<1>(lds, v * 4, sv[i]);
-                if (HIST) bad |= (int)(v >= Z) & (int)(v < a.length) & (int)(sv[i][0] < 0);
+                if (HIST) bad |= (int)((unsigned)(v - lcbase) >= (unsigned)Z) & (int)(v < a.length) & (int)(sv[i][0] < 0);
             }
             if (i0 + YB < NS) {
 #pragma unroll
@@ -246,7 +253,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     }
     float S0[ZR];
 #pragma unroll
-    for (int z = 0; z < ZR; z++) S0[z] = (z < ZR - 1 || zlast) ? 0.0f + yf[tid + z * TPB] : 0.0f;
+    for (int z = 0; z < ZR; z++) S0[z] = (z < ZR - 1 || zlast) ? 0.0f + yf[a.lc * Z + tid + z * TPB] : 0.0f;
     if (tid == 0) lds_flag[0] = 0;
     unsigned long long hist = 0;
     __syncthreads();
@@ -265,9 +272,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     // ---- outputs from S of iteration max_iter ----
 #pragma unroll
     for (int z = 0; z < ZR; z++)
-        if (z < ZR - 1 || zlast) { // column 0 comes back from the registers
+        if (z < ZR - 1 || zlast) { // column LC comes back from the registers
             const float sv[1] = {S0[z]};
-            lds_st<1>(lds, (tid + z * TPB) * 4, sv);
+            lds_st<1>(lds, (a.lc * Z + tid + z * TPB) * 4, sv);
         }
     __syncthreads();
     bad = 0;

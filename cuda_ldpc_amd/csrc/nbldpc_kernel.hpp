@@ -223,14 +223,22 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 #pragma unroll
         for (int d = D + 1; d < NACT; d++) sfx ^= c.m0[d];
         constexpr int CH = ((Q - 1) % 7 == 0) ? 7 : 1;
+        float2 pr[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (1 + i));
+#pragma unroll 1
         for (int k0 = 1; k0 < Q; k0 += CH) {
             float v[CH], sl[CH], ev[CH];
             int sy[CH];
 #pragma unroll
             for (int i = 0; i < CH; i++) {
-                const float2 pr = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (k0 + i));
-                v[i] = pr.x;
-                sy[i] = __mul24(sfx ^ __float_as_int(pr.y), c.TC); // v_mul_u32_u24: full rate (v_mul_lo_u32 is not)
+                v[i] = pr[i].x;
+                sy[i] = __mul24(sfx ^ __float_as_int(pr[i].y), c.TC); // v_mul_u32_u24: full rate (v_mul_lo_u32 is not)
+            }
+            {   // the next batch's pairs (the last round re-reads its own: no branch in the loop)
+                const int kn = (k0 + CH < Q) ? k0 + CH : k0;
+#pragma unroll
+                for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (kn + i));
             }
 #pragma unroll
             for (int i = 0; i < CH; i++) ev[i] = c.E[sy[i]];
@@ -348,20 +356,48 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         const int col = min(wave + ci * nwaves, N - 1);
         lch[ci] = active ? Lch[col * (q - 1) + lane] : 0.0f;
     }
+    // The graph does not change between iterations: for narrow codes (dv <= 2) each lane keeps, per column and edge, the
+    // LDS offset of ITS entry of the check thread's max array, E[mul(sym, h)][thr], so an iteration starts with that one
+    // read instead of three dependent table look-ups.  E[0][thr] (the reference's EMS_L_c2v[0]) is the same read in the
+    // lane that carries field element 0.
+    constexpr bool kInvariantOffsets = DVM <= 2;
+    int evoff[kInvariantOffsets ? CPW : 1][DVM];
+    unsigned wmask = 0; // bit ci*DVM + d: edge d of column ci exists
+    if constexpr (kInvariantOffsets) {
+#pragma unroll
+        for (int ci = 0; ci < CPW; ci++) {
+            const int col = min(wave + ci * nwaves, N - 1);
+            const int w = t_vn_w[col];
+#pragma unroll
+            for (int d = 0; d < DVM; d++) {
+                const int dd = min(d, dv - 1);
+                evoff[ci][d] = mulb[sym * q + t_vn_gf[col * dv + dd]] * TCP + t_vn_thr[col * dv + dd];
+                if (d < w) wmask |= 1u << (ci * DVM + d);
+            }
+        }
+    }
     // one variable node, lane <-> field element (LDPC_Decoder.cpp:202-251)
-    auto vn_column = [&](int col, float llr, bool store) {
+    auto vn_column = [&](int col, float llr, bool store, int ci) {
         const int w = t_vn_w[col];
         float c2[DVM];
 #pragma unroll
         for (int d = 0; d < DVM; d++) {
-            const int dd = min(d, dv - 1);
-            const int thr = t_vn_thr[col * dv + dd], h = t_vn_gf[col * dv + dd];
-            const float e0 = E[thr];
-            const float ev = E[mulb[sym * q + h] * TCP + thr];
-            float c;
-            c = nb_div12(ev - e0); // :309, double division
-            c2[d] = (d < w) ? c : 0.0f;
-            llr = (d < w) ? llr + c : llr;             // :208-213, ascending d
+            float e0, ev;
+            bool on;
+            if (kInvariantOffsets && ci >= 0) {
+                ev = E[evoff[kInvariantOffsets ? ci : 0][d]];
+                e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), Q - 1));
+                on = (wmask >> (ci * DVM + d)) & 1u;
+            } else {
+                const int dd = min(d, dv - 1);
+                const int thr = t_vn_thr[col * dv + dd], h = t_vn_gf[col * dv + dd];
+                e0 = E[thr];
+                ev = E[mulb[sym * q + h] * TCP + thr];
+                on = d < w;
+            }
+            const float c = nb_div12(ev - e0); // :309, double division
+            c2[d] = on ? c : 0.0f;
+            llr = on ? llr + c : llr;          // :208-213, ascending d
         }
         // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
         const float v = active ? llr : -__builtin_inff();
@@ -377,8 +413,15 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         }
     };
     int it = 0, ok = 0;
+#ifdef NB_STAMP
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define NB_T(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define NB_T(i)
+#endif
     while (it < a.max_iter) {
         it++;
+        NB_T(5)
         // ---- A: variable nodes ------------------------------------------------------------
         // The first CPW columns of a wave run as straight-line code on a clamped column index (only the stores are
         // conditional), so that their table look-ups, E gathers and double divisions overlap; L_ch stays in registers.
@@ -387,18 +430,22 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
 #pragma unroll
         for (int ci = 0; ci < CPW; ci++) {
             const int col = wv + ci * nwaves;
-            vn_column(min(col, N - 1), lch[ci], col < N);
-            __builtin_amdgcn_sched_barrier(0); // bounds the registers (1024 threads: 128 VGPRs)
+            vn_column(min(col, N - 1), lch[ci], col < N, ci);
+            if (ci & 1) __builtin_amdgcn_sched_barrier(0); // two columns in flight: bounds the registers (1024 threads: 128 VGPRs)
         }
-        for (int col = wave + CPW * nwaves; col < N; col += nwaves) vn_column(col, active ? Lch[col * (q - 1) + lane] : 0.0f, true);
+        for (int col = wave + CPW * nwaves; col < N; col += nwaves) vn_column(col, active ? Lch[col * (q - 1) + lane] : 0.0f, true, -1);
+        NB_T(0)
         __syncthreads();
+        NB_T(4)
         // ---- S: syndrome (:218-238) ----------------------------------------------------------
         if (tid < M) {
             int s = 0;
             for (int i = 0; i < t_cn_w[tid]; i++) s ^= mulb[outs[t_cn_vn[tid * dc + i]] * q + t_cn_gf[tid * dc + i]];
             if (s) flag[0] = 1;
         }
+        NB_T(1)
         __syncthreads();
+        NB_T(4)
         if (flag[0] == 0) {
             it--; // :236
             ok = 1;
@@ -412,7 +459,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
 #pragma unroll
             for (int i = 0; i < SW; i++) {
                 const int edge = e0 + i;
-                live[i] = edge < NE && (edge % dv) < t_vn_w[edge / dv];
+                live[i] = edge < NE && t_vn_gf[min(edge, NE - 1)] != 0; // unused slots carry coefficient 0, edges never do
                 const float val = (live[i] && lane < q) ? pairs[edge * PST + 2 * lane] : 0.0f;
                 // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
                 const uint32_t b = __float_as_uint(val + 0.0f);
@@ -433,7 +480,9 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
                 }
             }
         }
+        NB_T(2)
         __syncthreads();
+        NB_T(4)
         // ---- C: check nodes (:272-303) -----------------------------------------------------------
         if (tid < TC) {
             const int row = tid / dc, e = tid - row * dc, w = t_cn_w[row];
@@ -448,9 +497,18 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
                 }
             }
         }
+        NB_T(3)
         __syncthreads();
+        NB_T(4)
         if (tid == 0) flag[0] = 0; // next write is two barriers away, last read was two barriers ago
     }
+#ifdef NB_STAMP
+    if (tid == 0 && a.c2v && frame == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.c2v);
+        for (int i = 0; i < 6; i++) o[i] = tacc[i];
+    }
+    if (frame == 0) return;
+#endif
     // ---- outputs ------------------------------------------------------------------------------
     for (int i = tid; i < N; i += NT) a.out[(size_t)frame * N + i] = outs[i];
     if (tid == 0) {
