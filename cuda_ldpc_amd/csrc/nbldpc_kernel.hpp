@@ -64,7 +64,6 @@ __device__ __forceinline__ float nb_div12(float x)
     const double q0 = xd * r;
     const double e = __builtin_fma(-1.2, q0, xd);
     const float q = (float)__builtin_fma(e, r, q0);
-    if (NB_ABLATE & 32) return (float)((double)x / 1.2);
     return (x == 0.0f || __builtin_isinf(x)) ? x : q;
 }
 
@@ -87,8 +86,9 @@ __device__ __forceinline__ float nb_wave_max(float v)
 
 // 64-lane bitonic sort, descending, of the pairwise-distinct 64-bit keys (hi, lo).  One compare-exchange step:
 // the partner lane's key arrives through DPP (partners 1, 2, 8 lanes away: 14 of the 21 steps) or the LDS crossbar
-// (ds_swizzle / ds_bpermute: 4, 16, 32 lanes away), the compare is a 64-bit subtract-with-borrow chain on VCC, the
-// keep-max lane pattern of the step is a compile-time constant XORed into VCC on the scalar unit.
+// (ds_swizzle / ds_bpermute: 4, 16, 32 lanes away), the compare is one v_cmp_gt_u64, the keep-max lane pattern of
+// the step is a compile-time constant XNORed into the compare mask on the scalar unit.  Every step is checked
+// against a plain compare on the GPU (tests/cpp/dpp_step_test.hip).
 __host__ __device__ constexpr unsigned long long nb_keepmax_mask(int K, int J)
 {
     unsigned long long m = 0;
@@ -101,44 +101,27 @@ __host__ __device__ constexpr unsigned long long nb_keepmax_mask(int K, int J)
 template <int K, int J> __device__ __forceinline__ void nb_bitonic_step(uint32_t &hi, uint32_t &lo)
 {
     constexpr unsigned long long KM = nb_keepmax_mask(K, J);
-    if constexpr ((J == 1 || J == 2 || J == 8) && !(NB_ABLATE & 16)) {
-        // The partner lane (lane ^ J) is inside the lane's own row of 16: it is read through DPP as an operand of the
-        // compare and of the selects themselves -- no data movement instruction, no LDS crossbar.
-        //   vcc  = borrow of the 64-bit subtract-with-borrow chain over (mine, partner)
-        //   vcc  = ~(vcc ^ KM);   key = vcc ? mine : partner
-        // The polarity of this sequence is pinned by tests/cpp/dpp_step_test.hip (test_nbldpc_gpu.py), which checks every
-        // (K, J) step of the network against a plain 64-bit compare on the GPU.
-        uint32_t t;
-#define NB_DPP_STEP(CTRL)                                                                                         \
-        asm volatile("s_nop 1\n\t" /* a VALU write of %0 / %1 right before (the compiler's own code) -> DPP read: 2 wait states */ \
-                     "v_subrev_co_u32_dpp %2, vcc, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                  \
-                     "v_subbrev_co_u32_dpp %2, vcc, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"            \
-                     "s_xnor_b64 vcc, vcc, %3\n\t"                                                                \
-                     "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                    \
-                     "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                        \
-                     : "+v"(hi), "+v"(lo), "=&v"(t)                                                                \
-                     : "s"(KM)                                                                                     \
-                     : "vcc")
-        if constexpr (J == 1) NB_DPP_STEP("quad_perm:[1,0,3,2]");
-        else if constexpr (J == 2) NB_DPP_STEP("quad_perm:[2,3,0,1]");
-        else NB_DPP_STEP("row_ror:8");
-#undef NB_DPP_STEP
+    uint32_t phi, plo;
+    if constexpr (J == 1 || J == 2 || J == 8) {
+        // the partner lane (lane ^ J) is inside the lane's own row of 16: v_mov_b32_dpp, no LDS crossbar.  (Partners 4, 16
+        // and 32 lanes away could also stay on the VALU -- masked DPP pairs, v_permlane16/32_swap -- but the phase is bound
+        // by VALU issue, DPP and 3-operand instructions cost ~4.4 SIMD-cycles each (tools/valu_rate.hip): measured slower.)
+        constexpr int CTRL = (J == 1) ? 0xB1 /* quad_perm [1,0,3,2] */ : (J == 2) ? 0x4E /* quad_perm [2,3,0,1] */ : 0x128 /* row_ror:8 */;
+        phi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+        plo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    } else if constexpr (J < 32) {
+        phi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)hi, (J << 10) | 0x1f);
+        plo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)lo, (J << 10) | 0x1f);
     } else {
-        uint32_t phi, plo, t;
-        if constexpr (J < 32) {
-            phi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)hi, (J << 10) | 0x1f);
-            plo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)lo, (J << 10) | 0x1f);
-        } else {
-            phi = (uint32_t)__shfl_xor((int)hi, 32, 64);
-            plo = (uint32_t)__shfl_xor((int)lo, 32, 64);
-        }
-        // vcc = (partner > mine); take the partner's key where that equals "this lane keeps the larger one"
-        asm volatile("v_sub_co_u32 %2, vcc, %1, %4\n\tv_subb_co_u32 %2, vcc, %0, %3, vcc\n\ts_xnor_b64 vcc, vcc, %5\n\t"
-                     "v_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc"
-                     : "+v"(hi), "+v"(lo), "=&v"(t)
-                     : "v"(phi), "v"(plo), "s"(KM)
-                     : "vcc");
+        phi = (uint32_t)__shfl_xor((int)hi, 32, 64);
+        plo = (uint32_t)__shfl_xor((int)lo, 32, 64);
     }
+    // one 64-bit compare into a scalar mask (any SGPR pair: the sorts in flight do not queue on VCC), the step's
+    // keep-max lane pattern XNORed in on the scalar unit, two selects
+    const bool gt = (((unsigned long long)phi << 32) | plo) > (((unsigned long long)hi << 32) | lo);
+    const bool take = __builtin_amdgcn_inverse_ballot_w64(~(__builtin_amdgcn_ballot_w64(gt) ^ KM));
+    hi = take ? phi : hi;
+    lo = take ? plo : lo;
 }
 // W independent sorts advance through the network together: each step waits ~an LDS round trip for its
 // partner keys, so one sort alone is latency-bound; W of them fill that latency with each other's work.
