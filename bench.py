@@ -98,7 +98,11 @@ def pmc_onchip(kernel_name, kern_ms):
         if j.get("kernel") != kernel_name or "SQ_INSTS_VALU" not in sq:
             continue
         cycles = j["avg_ms"] * 1e-3 * 2.3e9 if not sq.get("GRBM_GUI_ACTIVE") else sq["GRBM_GUI_ACTIVE"] / 8.0
-        return {"valu_issue_util": sq["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cycles, "lds_array_util": sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles,
+        # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md, PMC units) of VALU execution summed over the 1024 SIMDs;
+        # a plain 2-operand instruction costs ~2.5 SIMD-cycles, 3-operand / DPP / 64-bit ones ~4.4 (tools/valu_rate.hip)
+        busy = sq.get("SQ_ACTIVE_INST_VALU")
+        return {"valu_busy": (busy * 4.0 / 1024.0 / cycles) if busy else None,
+                "valu_instructions_per_simd_cycle": sq["SQ_INSTS_VALU"] / 1024.0 / cycles, "lds_array_util": sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles,
                 "lds_bank_conflict_cycles": sq.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.basename(p),
                 "note": "profiled pass; kernel cycles from %s" % ("GRBM_GUI_ACTIVE/8" if sq.get("GRBM_GUI_ACTIVE") else "avg_ms * 2.3 GHz")}
     return None

@@ -86,8 +86,10 @@ def main():
     if out["read_bytes_per_launch"] and out["write_bytes_per_launch"]:
         out["hbm_bytes_per_launch"] = out["read_bytes_per_launch"] + out["write_bytes_per_launch"]
     if sq:
-        s, _ = counters(sq, match)
-        out["sq"] = s
+        out["sq"] = {}
+        for d in sq.split(","):  # several SQ passes (the counters of one pass are limited)
+            s, _ = counters(d, match)
+            out["sq"].update(s)
     kfile = os.path.join(here, "..", "gpurun_out", "%s_%s_bench.json" % (tag, name))
     if os.path.exists(kfile):
         try:
