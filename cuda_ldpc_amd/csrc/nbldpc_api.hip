@@ -271,6 +271,64 @@ extern "C" int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *cw,
     return NBLDPC_OK;
 }
 
+namespace {
+constexpr unsigned kNbA[3] = {249u, 251u, 252u}, kNbM[3] = {61967u, 63443u, 63599u}; // src/LDPC_Encoder.cpp:72-74
+
+__host__ __device__ inline unsigned nb_powmod(unsigned a, unsigned long long k, unsigned m)
+{
+    unsigned long long r = 1, b = a % m;
+    while (k) {
+        if (k & 1) r = (r * b) % m;
+        b = (b * b) % m;
+        k >>= 1;
+    }
+    return (unsigned)r;
+}
+
+// One thread per (frame b, run of kNbRun consecutive bits): jump to draw 4*(b*N*m + i0), then step as RandomModule does.
+constexpr int kNbRun = 16;
+__global__ __launch_bounds__(256) void k_nb_awgn(unsigned s0, unsigned s1, unsigned s2, float sigma, const int *cw, int N, int m, int B, float *rx)
+{
+    const int runs = (N * m + kNbRun - 1) / kNbRun;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)B * runs) return;
+    const int b = (int)(id / runs), i0 = (int)(id - (long long)b * runs) * kNbRun;
+    const unsigned long long k = 4ull * ((unsigned long long)b * N * m + i0);
+    unsigned s[3] = {s0, s1, s2};
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i] = (unsigned)(((unsigned long long)s[i] * nb_powmod(kNbA[i], k, kNbM[i])) % kNbM[i]);
+    const double two_pi = 2 * 3.1415926; // define.h:56
+    for (int i = i0; i < min(N * m, i0 + kNbRun); i++) {
+        float u[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) { // Real part: draws 1-2; Image part (unused for BPSK): draws 3-4 (LDPC_Encoder.cpp:59-66)
+#pragma unroll
+            for (int j = 0; j < 3; j++) s[j] = (s[j] * kNbA[j]) % kNbM[j];
+            float t = ((float)(int)s[0] / 61967.0f) + ((float)(int)s[1] / 63443.0f) + ((float)(int)s[2] / 63599.0f);
+            t -= (int)t;
+            u[d] = t;
+        }
+        const float tx = ((cw[i / m] >> (i % m)) & 1) ? -1.0f : 1.0f; // main.cu:203-209 + Constellation/BPSK.txt
+        const float amp = sqrtf(-2.0f * logf(1.0f - u[0]));
+        rx[(size_t)b * N * m + i] = (float)((double)sigma * cos(two_pi * (double)u[1]) * (double)amp + (double)tx);
+    }
+}
+} // namespace
+
+extern "C" int nbldpc_awgn_channel_device(int seed[3], float sigma, const int *cw, int N, int m, int B, float *rx, void *stream)
+{
+    if (!seed || !cw || !rx || N <= 0 || m <= 0 || B <= 0) return fail(NBLDPC_EINVAL, "nbldpc_awgn_channel_device: bad argument");
+    for (int i = 0; i < 3; i++)
+        if (seed[i] < 0 || (unsigned)seed[i] >= kNbM[i]) return fail(NBLDPC_EINVAL, "seed[%d]=%d outside [0,%u)", i, seed[i], kNbM[i]);
+    const long long threads = (long long)B * ((N * m + kNbRun - 1) / kNbRun);
+    hipLaunchKernelGGL(k_nb_awgn, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned)seed[0], (unsigned)seed[1],
+                       (unsigned)seed[2], sigma, cw, N, m, B, rx);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    const unsigned long long draws = 4ull * (unsigned long long)N * m * B;
+    for (int i = 0; i < 3; i++) seed[i] = (int)(((unsigned long long)seed[i] * nb_powmod(kNbA[i], draws, kNbM[i])) % kNbM[i]);
+    return NBLDPC_OK;
+}
+
 extern "C" float nbldpc_sigma(float snr, int snrtype, int n_qam, float rate)
 {
     if (snrtype == 0) return (float)std::sqrt(0.5 / (std::log((double)n_qam) / std::log(2.0) * rate * std::pow(10.0, (double)(snr / 10.0))));

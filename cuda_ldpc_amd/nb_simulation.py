@@ -13,6 +13,16 @@ import torch
 from . import nbldpc as nb
 
 
+class _SeedsAfter:
+    """seeds_before[b] of a device-generated batch, computed on demand by jump-ahead."""
+
+    def __init__(self, seed0, code):
+        self.seed0, self.code = seed0, code
+
+    def __getitem__(self, b):
+        return nb.seed_after(self.seed0, b, self.code)
+
+
 class NBSim:
     """The counters of class Simulation (include/struct.h:52-71) that the NB program uses."""
 
@@ -31,18 +41,25 @@ class NBSim:
 
 
 def Simulation_GPU(code, seed, sigma, SIM, CodeWord_sym, EMS_Nm=2, EMS_Nc=2, maxIT=20, batch=1024, leastErrorFrames=50,
-                   leastTestFrames=1000, max_frames=None, device=None):
-    """One Eb/N0 point. `seed` (int32[3]) advances exactly as far as the reference would have drawn."""
+                   leastTestFrames=1000, max_frames=None, device=None, device_channel=False):
+    """One Eb/N0 point. `seed` (int32[3]) advances exactly as far as the reference would have drawn.
+    device_channel: generate the noise on the GPU (same uniforms, device libm) instead of the host, frame by frame."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     cw = np.ascontiguousarray(CodeWord_sym, np.int32)
     cw_dev = torch.from_numpy(cw).to(device)
     while True:
-        seeds_before = []
-        rx = np.empty((batch, code.N * code.m), np.float32)
-        for b in range(batch):
-            seeds_before.append(seed.copy())
-            rx[b] = nb.AWGNChannel_CPU(seed, sigma, code, cw)
-        Lch = nb.Demodulate(code, torch.from_numpy(rx).to(device), sigma)
+        if device_channel:
+            seed0 = seed.copy()
+            seeds_before = _SeedsAfter(seed0, code)
+            rxt = nb.AWGNChannel_GPU(seed, sigma, code, cw_dev, batch)
+        else:
+            seeds_before = []
+            rx = np.empty((batch, code.N * code.m), np.float32)
+            for b in range(batch):
+                seeds_before.append(seed.copy())
+                rx[b] = nb.AWGNChannel_CPU(seed, sigma, code, cw)
+            rxt = torch.from_numpy(rx).to(device)
+        Lch = nb.Demodulate(code, rxt, sigma)
         r = nb.Decoding_EMS(code, Lch, EMS_Nm, EMS_Nc, maxIT)
         errs = (r["DecodeOutput"] != cw_dev[None, :]).sum(dim=1).cpu().numpy()
         its = r["iter_number"].cpu().numpy()

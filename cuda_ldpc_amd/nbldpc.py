@@ -23,6 +23,7 @@ lib.nbldpc_ems_decode_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int,
 lib.nbldpc_demodulate_bpsk.argtypes = [c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]
 lib.nbldpc_statistic.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
 lib.nbldpc_awgn_channel_host.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]
+lib.nbldpc_awgn_channel_device.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
 lib.nbldpc_sigma.restype = c_float
 lib.nbldpc_sigma.argtypes = [c_float, c_int, c_int, c_float]
 
@@ -130,6 +131,27 @@ def AWGNChannel_CPU(seed, sigma, code, CodeWord_sym):
     rx = np.empty(code.N * code.m, np.float32)
     _check(lib.nbldpc_awgn_channel_host(_np(seed), c_float(sigma), _np(cw), code.N, code.m, _np(rx)), "AWGNChannel_CPU")
     return rx
+
+
+def AWGNChannel_GPU(seed, sigma, code, CodeWord_sym_dev, B, stream=None):
+    """Device-side Modulate + AWGNChannel for B consecutive frames of the same stream (LCG jump-ahead: the uniforms are
+    the reference's, the samples may differ from the host libm's by an ulp).  Returns rx CUDA float32 [B, N*m]; seed
+    advanced exactly like B calls of AWGNChannel_CPU."""
+    if not (isinstance(seed, np.ndarray) and seed.dtype == np.int32 and seed.size == 3):
+        raise ValueError("seed must be an int32 numpy array of 3")
+    if not (CodeWord_sym_dev.is_cuda and CodeWord_sym_dev.dtype == torch.int32 and CodeWord_sym_dev.numel() == code.N):
+        raise ValueError("CodeWord_sym_dev must be a CUDA int32 tensor of N symbols")
+    rx = torch.empty((B, code.N * code.m), dtype=torch.float32, device=CodeWord_sym_dev.device)
+    st = c_void_p((stream or torch.cuda.current_stream(rx.device)).cuda_stream)
+    _check(lib.nbldpc_awgn_channel_device(_np(seed), c_float(sigma), _dev(CodeWord_sym_dev), code.N, code.m, B, _dev(rx), st), "AWGNChannel_GPU")
+    return rx
+
+
+def seed_after(seed, frames, code):
+    """The RandomModule state after `frames` more frames (4 draws per bit): what the reference's seed would be."""
+    a, m = (249, 251, 252), (61967, 63443, 63599)
+    k = 4 * code.N * code.m * int(frames)
+    return np.array([(int(seed[i]) * pow(a[i], k, m[i])) % m[i] for i in range(3)], np.int32)
 
 
 def sigma_of(SNR, rate, snrtype=0, n_QAM=2):

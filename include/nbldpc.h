@@ -83,6 +83,14 @@ int nbldpc_statistic(const nbldpc_code *code, const int *DecodeOutput, const int
  * ONE frame; seed[3] advanced in place. */
 int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *CodeWord_sym, int N, int m, float *rx);
 
+/* Device-side input generator: the same stream for B consecutive frames.  Every (frame, bit) jumps the
+ * three LCGs of RandomModule (src/LDPC_Encoder.cpp:70-79) ahead to its own first draw (draw 4*(b*N*m + i):
+ * seed * a^k mod m), so the uniforms are the reference's exactly; the samples are then formed with the device's
+ * logf / sqrtf / cos, which may differ from the host libm by an ulp on a small fraction of arguments.
+ * CodeWord_sym: DEVICE int32 [N]; rx: DEVICE float [B][N*m]; seed[3] (host) is advanced by B whole frames exactly
+ * like B calls of nbldpc_awgn_channel_host. */
+int nbldpc_awgn_channel_device(int seed[3], float sigma, const int *CodeWord_sym, int N, int m, int B, float *rx, void *stream);
+
 /* sigma of a sweep point (src/main.cu:221-228). */
 float nbldpc_sigma(float SNR, int snrtype, int n_QAM, float rate);
 

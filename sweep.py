@@ -72,8 +72,9 @@ def main():
         cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
         print("# BDS.576.288.GF.64 N=%d symbols GF(%d), EMS(2,2), maxIT=%d" % (code.N, code.q, args.iters or 20))
         print("# SNR      NTF   NEF         FER         BER  AverIT")
-        sweep(code, cw, args.start, args.stop, args.step, maxIT=args.iters or 20, batch=min(args.batch, 1024),
-              max_frames=None if args.max_batches is None else args.max_batches * min(args.batch, 1024))
+        nbatch = args.batch if args.device_channel else min(args.batch, 1024)  # the host channel is serial: keep its batches small
+        sweep(code, cw, args.start, args.stop, args.step, maxIT=args.iters or 20, batch=nbatch,
+              max_frames=None if args.max_batches is None else args.max_batches * nbatch, device_channel=args.device_channel)
     if world > 1:
         dist.destroy_process_group()
 
