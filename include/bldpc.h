@@ -41,7 +41,8 @@ extern "C" {
 /* kernel selection */
 #define BLDPC_KERNEL_AUTO 0   /* QC_LDS when the code has QC structure and fits LDS, else TABLE */
 #define BLDPC_KERNEL_TABLE 1  /* generic address-table kernels, messages resident in HBM; any table      */
-#define BLDPC_KERNEL_QC_LDS 2 /* fused QC kernel, all iterations on-chip, messages resident in LDS       */
+#define BLDPC_KERNEL_QC_LDS 2 /* fused QC kernels, all iterations on-chip: messages in LDS, or (larger codes)  *
+                               * compressed check states in LDS / in registers with the a-posteriori values in LDS */
 
 typedef struct bldpc_code bldpc_code; /* opaque: device-resident code tables + cached workspace.  A code object owns
                                         * its scratch buffers: use it from one host thread / one stream at a time (create
