@@ -193,11 +193,16 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
         }
         // ---- ... + y closes every sum (:205): one aligned pass, channel values re-read (L2-resident).  The pass also
         // sweeps column LC's unused words (1/L of it) rather than special-casing them.
-        int bad = 0;
+        // flag bookkeeping (HIST): OR of the sign bits of the values that lie inside the first `length` variables and
+        // outside column LC's unused words.  `lim` is made opaque per iteration: the range tests are loop-invariant and
+        // would otherwise be hoisted, one register per stride, and spilled.
+        unsigned badbits = 0;
+        int lim = a.length - tid, lcrel = lcbase - tid;
+        if (HIST) asm volatile("" : "+v"(lim), "+v"(lcrel));
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
             S0[z] = acc0[z] + y_lc(z);
-            if (HIST) bad |= (int)(lcbase + tid + z * TPB < a.length) & (int)(S0[z] < 0);
+            if (HIST) badbits |= f2u(S0[z]) & (unsigned)((lcbase + z * TPB - lim) >> 31);
         }
 #pragma unroll
         for (int i0 = 0; i0 < NS; i0 += YB) {
@@ -213,7 +218,11 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
                 const int v = tid + (i0 + i) * TPB;
                 sv[i][0] += yv[i];
                 lds_st<1>(lds, v * 4, sv[i]);
-                if (HIST) bad |= (int)((unsigned)(v - lcbase) >= (unsigned)Z) & (int)(v < a.length) & (int)(sv[i][0] < 0);
+                if (HIST) { // v < length and v outside [lcbase, lcbase + Z), with v = tid + (i0 + i) * TPB
+                    const int k = (i0 + i) * TPB;
+                    const unsigned in_len = (unsigned)((k - lim) >> 31), in_lc = ((unsigned)(k - lcrel) < (unsigned)Z) ? ~0u : 0u;
+                    badbits |= f2u(sv[i][0]) & in_len & ~in_lc;
+                }
             }
             if (i0 + YB < NS) {
 #pragma unroll
@@ -221,7 +230,7 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (HIST && bad) lds_flag[0] = 1;
+        if (HIST && (badbits >> 31)) lds_flag[0] = 1;
         __syncthreads();
         if (HIST && it + 1 < a.max_iter) flags_collect(it + 1);
     }
