@@ -4,7 +4,7 @@
 TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference
 for the NB part):  python oracle/make_golden.py
 
-NB EMS  (tests/golden/nb_ref_<snr>dB.npz): outputs of the REFERENCE's own CPU
+NB EMS / TMM / layered TMM  (tests/golden/nb_ref[_tmm|_ltmm]_<snr>dB.npz): outputs of the REFERENCE's own CPU
   decoder (oracle/_ref/nb_ref, compiled from /root/reference/myNBLDPC/src/*.cpp)
   for the first 16 frames of the seed-173 stream at Eb/N0 = 2, 3 and 5 dB:
   channel samples rx, DecodeOutput, iter_number, return flag, fold hashes of
@@ -34,7 +34,8 @@ FULL_FRAMES = {2.0: [0], 3.0: [0, 1, 4], 5.0: [0]}
 def parse_nb_dump(path):
     b = open(path, "rb").read()
     hdr = np.frombuffer(b[:32], np.int32)
-    N, M, q, dv, dc, maxit, nf, _ = (int(x) for x in hdr)
+    N, M, q, dv, dc, maxit, nf, method = (int(x) for x in hdr)
+    nv = q - 1 if method == 0 else q  # the trellis decoders keep element 0 in their vectors
     sigma, rate = np.frombuffer(b[32:40], np.float32)
     off = 40
     cw = np.frombuffer(b[off:off + 4 * N], np.int32).copy(); off += 4 * N
@@ -46,14 +47,15 @@ def parse_nb_dump(path):
         r["Lch"] = np.frombuffer(b[off:off + 4 * N * (q - 1)], np.float32).reshape(N, q - 1).copy(); off += 4 * N * (q - 1)
         r["out"] = np.frombuffer(b[off:off + 4 * N], np.int32).copy(); off += 4 * N
         r["it"], r["ok"] = (int(x) for x in np.frombuffer(b[off:off + 8], np.int32)); off += 8
-        r["LLR"] = np.frombuffer(b[off:off + 4 * N * (q - 1)], np.float32).reshape(N, q - 1).copy(); off += 4 * N * (q - 1)
-        r["c2v"] = np.frombuffer(b[off:off + 4 * M * dc * (q - 1)], np.float32).reshape(M, dc, q - 1).copy(); off += 4 * M * dc * (q - 1)
+        r["LLR"] = np.frombuffer(b[off:off + 4 * N * nv], np.float32).reshape(N, nv).copy(); off += 4 * N * nv
+        r["c2v"] = np.frombuffer(b[off:off + 4 * M * dc * nv], np.float32).reshape(M, dc, nv).copy(); off += 4 * M * dc * nv
         recs.append(r)
     assert off == len(b)
     return dict(N=N, M=M, q=q, dv=dv, dc=dc, maxit=maxit, sigma=float(sigma), rate=float(rate), cw=cw, recs=recs)
 
 
-def make_nb():
+def make_nb(method=0, tag="nb_ref"):
+    """method = the reference's decoder_method: 0 Decoding_EMS, 1 Decoding_TMM, 3 Decoding_layered_TMM."""
     ref = orc.ref_binary()
     if ref is None:
         print("oracle/_ref/nb_ref missing -> NB golden not regenerated")
@@ -61,13 +63,13 @@ def make_nb():
     for snr in (2.0, 3.0, 5.0):
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "d.bin")
-            subprocess.check_call([ref, "dump", str(snr), "16", out], cwd=os.path.join(ROOT, "data", "nb"),
+            subprocess.check_call([ref, "dump", str(snr), "16", out, str(method)], cwd=os.path.join(ROOT, "data", "nb"),
                                   stdout=subprocess.DEVNULL)
             d = parse_nb_dump(out)
         recs = d["recs"]
         full = FULL_FRAMES[snr]
         np.savez_compressed(
-            os.path.join(GOLD, "nb_ref_%gdB.npz" % snr),
+            os.path.join(GOLD, "%s_%gdB.npz" % (tag, snr)),
             snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"],
             rx=np.stack([r["rx"] for r in recs]), out=np.stack([r["out"] for r in recs]),
             it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
@@ -77,7 +79,7 @@ def make_nb():
             full_frames=np.array(full, np.int32),
             full_Lch=np.stack([recs[i]["Lch"] for i in full]), full_LLR=np.stack([recs[i]["LLR"] for i in full]),
             full_c2v=np.stack([recs[i]["c2v"] for i in full]))
-        print("NB %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+        print("NB %s %.1f dB: iters" % (tag, snr), [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
     np.savetxt(os.path.join(ROOT, "data", "nb", "codeword_bds_gf64.txt"), d["cw"][None, :], fmt="%d")
 
 
@@ -111,3 +113,5 @@ if __name__ == "__main__":
     orc.build()
     make_binary()
     make_nb()
+    make_nb(1, "nb_ref_tmm")
+    make_nb(3, "nb_ref_ltmm")

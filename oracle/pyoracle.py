@@ -186,6 +186,19 @@ def nb_ems_decode(code, Lch, Nm=2, Nc=2, max_iter=20, dcmax_cfg=None, want_state
     return dict(out=out, it=it.value, ok=int(ok), LLR=LLR, c2v=c2v)
 
 
+def nb_tmm_decode(code, Lch, max_iter=20, layered=False, want_state=False):
+    """Decoding_TMM / Decoding_layered_TMM (decoder_method 1 / 3).  State: LLR [N][q], c2v [M][dc][q]."""
+    Lch = np.ascontiguousarray(Lch, np.float32)
+    out = np.zeros(code.N, np.int32)
+    it = c_int(0)
+    LLR = np.zeros((code.N, code.q), np.float32) if want_state else None
+    c2v = np.zeros((code.M, code.dc, code.q), np.float32) if want_state else None
+    ok = lib().orc_nb_tmm_decode(code.N, code.M, code.q, code.dv, code.dc, _p(code.vn_w), _p(code.vn_cn), _p(code.cn_w), _p(code.cn_vn),
+                                 _p(code.cn_gf), _p(code.mul), _p(code.inv), _p(Lch), 1 if layered else 0, max_iter, _p(out),
+                                 ctypes.byref(it), _p(LLR), _p(c2v))
+    return dict(out=out, it=it.value, ok=int(ok), LLR=LLR, c2v=c2v)
+
+
 def nb_ems_decode_batch(code, Lch, Nm=2, Nc=2, max_iter=20, dcmax_cfg=None):
     Lch = np.ascontiguousarray(Lch, np.float32)
     B = Lch.shape[0]

@@ -17,8 +17,10 @@
  * paths (define.h:23-24, GF.cpp:81): BDS.576.288.GF.64.txt,
  * Constellation/BPSK.txt, GF/Arith.Table.GF.64.txt  (here: data/nb/).
  *
- * usage: nb_ref dump  <snr_db> <nframes> <out.bin>
- *        nb_ref time  <snr_db> <nframes>            -> prints frames/s of Decoding_EMS
+ * usage: nb_ref dump  <snr_db> <nframes> <out.bin> [method]
+ *        nb_ref time  <snr_db> <nframes> [method]    -> prints frames/s of the decoder
+ * method = the reference's decoder_method (define.h:37): 0 Decoding_EMS (default), 1 Decoding_TMM,
+ * 3 Decoding_layered_TMM; the trellis decoders keep q entries per vector (element 0 included), the dump follows.
  */
 #include "define.h"
 #include "LDPC_Decoder.h"
@@ -36,6 +38,8 @@ int main(int argc, char **argv)
     const bool dump = strcmp(argv[1], "dump") == 0;
     const float snr = (float)atof(argv[2]);
     const int nframes = atoi(argv[3]);
+    const int method = dump ? (argc > 5 ? atoi(argv[5]) : 0) : (argc > 4 ? atoi(argv[4]) : 0);
+    const int NV = (method == 0) ? GFQ - 1 : GFQ; // entries per message vector in the dump
     FILE *out = NULL;
     if (dump) {
         if (argc < 5) return 2;
@@ -78,7 +82,7 @@ int main(int argc, char **argv)
     double secs = 0;
     long iters = 0;
     if (dump) {
-        int hdr[8] = {H->Variablenode_num, H->Checknode_num, GFQ, maxdv, maxdc, maxIT, nframes, 0};
+        int hdr[8] = {H->Variablenode_num, H->Checknode_num, GFQ, maxdv, maxdc, maxIT, nframes, method};
         float fh[2] = {AWGN->sigma, H->rate};
         fwrite(hdr, sizeof(int), 8, out);
         fwrite(fh, sizeof(float), 2, out);
@@ -92,7 +96,9 @@ int main(int argc, char **argv)
             for (int i = 0; i < H->Variablenode_num; i++) fwrite(Variablenode[i].L_ch, sizeof(float), GFQ - 1, out);
         }
         auto t0 = std::chrono::steady_clock::now();
-        int ok = Decoding_EMS(H, Variablenode, Checknode, EMS_NM, EMS_NC, DecodeOutput, iter_number);
+        int ok = (method == 1)   ? Decoding_TMM(H, Variablenode, Checknode, EMS_NM, EMS_NC, DecodeOutput, iter_number)
+                 : (method == 3) ? Decoding_layered_TMM(H, Variablenode, Checknode, EMS_NM, EMS_NC, DecodeOutput, iter_number)
+                                 : Decoding_EMS(H, Variablenode, Checknode, EMS_NM, EMS_NC, DecodeOutput, iter_number);
         auto t1 = std::chrono::steady_clock::now();
         secs += std::chrono::duration<double>(t1 - t0).count();
         iters += iter_number;
@@ -100,11 +106,11 @@ int main(int argc, char **argv)
             fwrite(DecodeOutput, sizeof(int), H->Variablenode_num, out);
             fwrite(&iter_number, sizeof(int), 1, out);
             fwrite(&ok, sizeof(int), 1, out);
-            for (int i = 0; i < H->Variablenode_num; i++) fwrite(Variablenode[i].LLR, sizeof(float), GFQ - 1, out);
+            for (int i = 0; i < H->Variablenode_num; i++) fwrite(Variablenode[i].LLR, sizeof(float), NV, out);
             for (int r = 0; r < H->Checknode_num; r++)
                 for (int d = 0; d < maxdc; d++) {
                     static float zeros[GFQ];
-                    fwrite(d < Checknode[r].weight ? Checknode[r].L_c2v[d] : zeros, sizeof(float), GFQ - 1, out);
+                    fwrite(d < Checknode[r].weight ? Checknode[r].L_c2v[d] : zeros, sizeof(float), NV, out);
                 }
         }
     }

@@ -127,6 +127,29 @@ def test_nb_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr):
             assert np.array_equal(r["c2v"].view(np.uint32), g["full_c2v"][i].view(np.uint32))
 
 
+@pytest.mark.parametrize("snr", [2, 3, 5])
+@pytest.mark.parametrize("layered", [False, True])
+def test_nb_tmm_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr, layered):
+    """Decoding_TMM / Decoding_layered_TMM (decoder_method 1 / 3): the restatement against the reference's own
+    functions (oracle/_ref/nb_ref dump ... 1|3), 16 frames per Eb/N0: symbols, iteration counts, return flags and the
+    final LLR / L_c2v state bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%s_%ddB.npz" % ("ltmm" if layered else "tmm", snr)))
+    c = nbcode
+    full = {int(f): i for i, f in enumerate(g["full_frames"])}
+    for fr in range(g["rx"].shape[0]):
+        Lch = orc.nb_demodulate(c, g["rx"][fr], float(g["sigma"]))
+        assert orc.fold_hash(Lch) == int(g["Lch_hash"][fr])
+        r = orc.nb_tmm_decode(c, Lch, int(g["maxit"]), layered=layered, want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]), "frame %d" % fr
+        assert np.array_equal(r["out"], g["out"][fr])
+        assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]), "LLR frame %d" % fr
+        assert orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr]), "c2v frame %d" % fr
+        if fr in full:
+            i = full[fr]
+            assert np.array_equal(r["LLR"].view(np.uint32), g["full_LLR"][i].view(np.uint32))
+            assert np.array_equal(r["c2v"].view(np.uint32), g["full_c2v"][i].view(np.uint32))
+
+
 def test_nb_survey_anchor_values(orc, nbcode):
     # SURVEY Appendix D.3: 3 dB, frame 0..3, L_ch of symbol 0 element 1; iteration counts
     g = np.load(os.path.join(GOLDEN, "nb_ref_3dB.npz"))
