@@ -6,6 +6,7 @@
 // src/LDPC_Encoder.cpp:41-79 and src/main.cu:203-228.
 #include "../../include/nbldpc.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 
 #include "common.hpp"
 #include "nbldpc_kernel.hpp"
+#include "nbldpc_tmm_kernel.hpp"
 
 using namespace cldpc;
 
@@ -23,6 +25,10 @@ struct nbldpc_code {
     int *d_cn_w = nullptr, *d_cn_src = nullptr, *d_cn_gf = nullptr, *d_cn_vn = nullptr;
     unsigned char *d_mul = nullptr;
     size_t lds_bytes = 0;
+    // trellis min-max decoders (nbldpc_tmm_decode_batch)
+    int *d_cn_hinv = nullptr, *d_row_order = nullptr, *d_level_begin = nullptr;
+    int levels = 0;
+    bool tmm_ok = false;
 };
 
 extern "C" const char *nbldpc_last_error(void) { return err_buf(); }
@@ -187,6 +193,42 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     if (!r) r = up((void **)&c->d_cn_gf, cn_gf, (size_t)M * dc * sizeof(int));
     if (!r) r = up((void **)&c->d_cn_vn, cn_vn, (size_t)M * dc * sizeof(int));
     if (!r) r = up((void **)&c->d_mul, mulb.data(), mulb.size());
+    // trellis min-max decoders: inverse of every edge coefficient; dependency levels of the rows for the layered schedule
+    // (level of a row = 1 + the highest level among the EARLIER rows that share a variable node with it)
+    if (!r) {
+        std::vector<int> hinv((size_t)M * dc, 0), level(M, 0), last(N, -1), order(M), lbegin;
+        bool inv_ok = true;
+        for (int i = 0; i < M * dc; i++) {
+            const int h = cn_gf[i];
+            if (h <= 0) continue;
+            int b = 0;
+            for (int x = 1; x < q && !b; x++)
+                if (mul[(size_t)h * q + x] == 1) b = x;
+            if (!b) inv_ok = false;
+            hinv[i] = b;
+        }
+        int levels = 0;
+        for (int row = 0; row < M; row++) {
+            int lv = 0;
+            for (int t = 0; t < cn_w[row]; t++) lv = std::max(lv, last[cn_vn[row * dc + t]] + 1);
+            for (int t = 0; t < cn_w[row]; t++) last[cn_vn[row * dc + t]] = lv;
+            level[row] = lv;
+            levels = std::max(levels, lv + 1);
+        }
+        for (int i = 0; i < M; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return level[x] < level[y]; });
+        lbegin.assign(levels + 1, 0);
+        for (int i = 0; i < M; i++) lbegin[level[i] + 1]++;
+        for (int l = 0; l < levels; l++) lbegin[l + 1] += lbegin[l];
+        c->levels = levels;
+        c->tmm_ok = inv_ok && dc <= kTmmMaxW && levels <= 63 && M <= kTmmThreads &&
+                    tmm_lds_bytes(N, M, q, dv, dc, false) <= 160 * 1024;
+        if (c->tmm_ok) {
+            if (!r) r = up((void **)&c->d_cn_hinv, hinv.data(), hinv.size() * sizeof(int));
+            if (!r) r = up((void **)&c->d_row_order, order.data(), order.size() * sizeof(int));
+            if (!r) r = up((void **)&c->d_level_begin, lbegin.data(), lbegin.size() * sizeof(int));
+        }
+    }
     if (!r) {
         hipError_t e = hipSuccess;
         e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -200,7 +242,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
 extern "C" int nbldpc_code_destroy(nbldpc_code *c)
 {
     if (!c) return NBLDPC_OK;
-    void *ptrs[] = {c->d_vn_w, c->d_vn_thr, c->d_vn_gf, c->d_cn_w, c->d_cn_src, c->d_cn_gf, c->d_cn_vn, c->d_mul};
+    void *ptrs[] = {c->d_vn_w, c->d_vn_thr, c->d_vn_gf, c->d_cn_w, c->d_cn_src, c->d_cn_gf, c->d_cn_vn, c->d_mul, c->d_cn_hinv, c->d_row_order, c->d_level_begin};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -221,6 +263,33 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     a.dcmax_cfg = maxdc_cfg > 0 ? maxdc_cfg : c->dc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    return NBLDPC_OK;
+}
+
+using TmmKernel = void (*)(TmmArgs);
+static TmmKernel tmm_kernel(int q, bool layered)
+{
+    if (q == 64) return layered ? k_nb_tmm<64, true> : k_nb_tmm<64, false>;
+    if (q == 32) return layered ? k_nb_tmm<32, true> : k_nb_tmm<32, false>;
+    return layered ? k_nb_tmm<16, true> : k_nb_tmm<16, false>;
+}
+
+extern "C" int nbldpc_tmm_decode_batch(nbldpc_code *c, const float *Lch, int B, int layered, int maxIT, int *out, int *iters, int *ok,
+                                       float *LLR, float *c2v, void *stream)
+{
+    if (!c || !Lch || !out || !iters || !ok) return fail(NBLDPC_EINVAL, "nbldpc_tmm_decode_batch: null argument");
+    if (B <= 0 || maxIT <= 0) return fail(NBLDPC_EINVAL, "B=%d maxIT=%d must be positive", B, maxIT);
+    if (!c->tmm_ok) return fail(NBLDPC_EUNSUPPORTED, "trellis min-max kernel unavailable for this code (dcmax > %d, > 63 row levels, or state exceeds LDS)", kTmmMaxW);
+    TmmArgs a;
+    a.Lch = Lch; a.out = out; a.iters = iters; a.ok = ok; a.LLR = LLR; a.c2v = c2v;
+    a.vn_w = c->d_vn_w; a.vn_thr = c->d_vn_thr; a.cn_w = c->d_cn_w; a.cn_src = c->d_cn_src; a.cn_gf = c->d_cn_gf; a.cn_vn = c->d_cn_vn;
+    a.cn_hinv = c->d_cn_hinv; a.row_order = c->d_row_order; a.level_begin = c->d_level_begin; a.mul = c->d_mul;
+    a.N = c->N; a.M = c->M; a.q = c->q; a.dv = c->dv; a.dc = c->dc; a.B = B; a.max_iter = maxIT; a.levels = c->levels;
+    const size_t lds = tmm_lds_bytes(c->N, c->M, c->q, c->dv, c->dc, layered != 0);
+    TmmKernel k = tmm_kernel(c->q, layered != 0);
+    CLDPC_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), NBLDPC_EHIP);
+    hipLaunchKernelGGL(k, dim3(B), dim3(kTmmThreads), lds, (hipStream_t)stream, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }

@@ -20,6 +20,7 @@ lib.nbldpc_gf_generate.argtypes = [c_int, ctypes.c_uint, c_void_p, c_void_p, c_v
 lib.nbldpc_code_create.argtypes = [c_int] * 5 + [c_void_p] * 7 + [ctypes.POINTER(c_void_p)]
 lib.nbldpc_code_destroy.argtypes = [c_void_p]
 lib.nbldpc_ems_decode_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 6
+lib.nbldpc_tmm_decode_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6
 lib.nbldpc_demodulate_bpsk.argtypes = [c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]
 lib.nbldpc_statistic.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
 lib.nbldpc_awgn_channel_host.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]
@@ -109,6 +110,25 @@ def Decoding_EMS(code, L_ch, EMS_Nm=2, EMS_Nc=2, maxIT=20, maxdc=0, want_state=F
     st = c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
     _check(lib.nbldpc_ems_decode_batch(code._h, _dev(L_ch), B, EMS_Nm, EMS_Nc, maxIT, maxdc, _dev(out), _dev(iters), _dev(ok),
                                        _dev(LLR), _dev(c2v), st), "Decoding_EMS")
+    return dict(DecodeOutput=out, iter_number=iters, ok=ok, LLR=LLR, L_c2v=c2v)
+
+
+def Decoding_TMM(code, L_ch, maxIT=20, layered=False, want_state=False, stream=None):
+    """Decoding_TMM (LDPC_Decoder.cpp:361-558) / Decoding_layered_TMM (:560-702, layered=True) for a batch.
+    Returns the same dict as Decoding_EMS; LLR [B,N,q] and L_c2v [B,M,dc,q] carry all q entries per vector."""
+    if not (L_ch.is_cuda and L_ch.dtype == torch.float32 and L_ch.is_contiguous()):
+        raise ValueError("L_ch must be a contiguous CUDA float32 tensor")
+    if L_ch.dim() != 3 or L_ch.shape[1] != code.N or L_ch.shape[2] != code.q - 1:
+        raise ValueError("L_ch must be [B, N=%d, q-1=%d]" % (code.N, code.q - 1))
+    B, dev = int(L_ch.shape[0]), L_ch.device
+    out = torch.empty((B, code.N), dtype=torch.int32, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    ok = torch.empty(B, dtype=torch.int32, device=dev)
+    LLR = torch.empty((B, code.N, code.q), dtype=torch.float32, device=dev) if want_state else None
+    c2v = torch.empty((B, code.M, code.dc, code.q), dtype=torch.float32, device=dev) if want_state else None
+    st = c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
+    _check(lib.nbldpc_tmm_decode_batch(code._h, _dev(L_ch), B, 1 if layered else 0, maxIT, _dev(out), _dev(iters), _dev(ok), _dev(LLR),
+                                       _dev(c2v), st), "Decoding_TMM")
     return dict(DecodeOutput=out, iter_number=iters, ok=ok, LLR=LLR, L_c2v=c2v)
 
 

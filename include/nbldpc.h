@@ -67,6 +67,17 @@ int nbldpc_code_destroy(nbldpc_code *code);
 int nbldpc_ems_decode_batch(nbldpc_code *code, const float *L_ch, int B, int EMS_Nm, int EMS_Nc, int maxIT, int maxdc_cfg,
                             int *DecodeOutput, int *iter_number, int *ok, float *LLR, float *L_c2v, void *stream);
 
+/* Trellis min-max decoders for a batch of frames: Decoding_TMM (decoder_method 1, myNBLDPC/src/LDPC_Decoder.cpp:361-558,
+ * flooding) and Decoding_layered_TMM (decoder_method 3, :560-702; layered != 0), called from decode_once_cpu/gpu
+ * (src/Simulation.cpp:58-70, :132-143) with the same arguments as Decoding_EMS.  Same outputs and return convention as
+ * nbldpc_ems_decode_batch (ok = 1: zero syndrome reached, iter_number already decremented).  Optional state outputs hold
+ * the reference's VN[].LLR and CN[].L_c2v after the call with ALL q entries per vector (element 0 included):
+ * LLR DEVICE float [B][N][q], L_c2v DEVICE float [B][M][dcmax][q]; NULL to skip.  The layered schedule visits the
+ * rows in dependency levels (rows that share no variable node commute), which leaves every value and its order of
+ * computation per variable as in the reference's row-by-row loop. */
+int nbldpc_tmm_decode_batch(nbldpc_code *code, const float *L_ch, int B, int layered, int maxIT, int *DecodeOutput, int *iter_number,
+                            int *ok, float *LLR, float *L_c2v, void *stream);
+
 /* Replaces Demodulate, BPSK branch (src/LDPC_Decoder.cpp:132-157), on the device:
  * rx float [B][N*m] (m = log2 q, bit b of symbol s at s*m+b) -> L_ch float [B][N][q-1]. */
 int nbldpc_demodulate_bpsk(const nbldpc_code *code, const float *rx, float sigma, int B, float *L_ch, void *stream);

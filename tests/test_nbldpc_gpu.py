@@ -217,3 +217,61 @@ def test_device_channel_same_draws_as_host(nb, code):
     rx_h2 = nb.AWGNChannel_CPU(s_host, sigma, code, cw)
     rx_d2 = nb.AWGNChannel_GPU(s_dev, sigma, code, torch.from_numpy(cw).cuda(), 1).cpu().numpy()[0]
     assert np.abs(rx_h2 - rx_d2).max() < 1e-6 and np.array_equal(s_host, s_dev)
+
+
+@pytest.mark.parametrize("snr", [2, 3, 5])
+@pytest.mark.parametrize("layered", [False, True])
+def test_tmm_matches_reference_dump(nb, code, orc, snr, layered):
+    """Trellis min-max decoders (decoder_method 1 / 3) against the reference's own Decoding_TMM / Decoding_layered_TMM:
+    symbols, iteration counts, return flags and the final LLR / L_c2v state of 16 frames per Eb/N0, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%s_%ddB.npz" % ("ltmm" if layered else "tmm", snr)))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"]))
+    r = nb.Decoding_TMM(code, Lch, int(g["maxit"]), layered=layered, want_state=True)
+    torch.cuda.synchronize()
+    out, it, ok = r["DecodeOutput"].cpu().numpy(), r["iter_number"].cpu().numpy(), r["ok"].cpu().numpy()
+    LLR, c2v = r["LLR"].cpu().numpy(), r["L_c2v"].cpu().numpy()
+    assert np.array_equal(it, g["it"]) and np.array_equal(ok, g["ok"])
+    assert np.array_equal(out, g["out"])
+    for fr in range(out.shape[0]):
+        assert orc.fold_hash(LLR[fr]) == int(g["LLR_hash"][fr]), "LLR frame %d" % fr
+        assert orc.fold_hash(c2v[fr]) == int(g["c2v_hash"][fr]), "c2v frame %d" % fr
+    for i, fr in enumerate(g["full_frames"]):
+        assert np.array_equal(LLR[fr].view(np.uint32), g["full_LLR"][i].view(np.uint32))
+        assert np.array_equal(c2v[fr].view(np.uint32), g["full_c2v"][i].view(np.uint32))
+
+
+@pytest.mark.parametrize("layered", [False, True])
+def test_tmm_ties_and_extremes_vs_oracle(nb, code, ocode, orc, layered):
+    """Heavy ties (first-minimum rules, first-best path), zeros, huge and denormal inputs; per-iteration states."""
+    rng = np.random.default_rng(5)
+    B = 4
+    Lch = rng.integers(-3, 4, size=(B, code.N, code.q - 1)).astype(np.float32)
+    Lch[0, :, ::5] = -0.0
+    Lch[1] *= 1e30
+    Lch[2] *= 1e-40
+    for maxit in (1, 2, 6):
+        r = nb.Decoding_TMM(code, torch.from_numpy(Lch).cuda(), maxit, layered=layered, want_state=True)
+        torch.cuda.synchronize()
+        for b in range(B):
+            want = orc.nb_tmm_decode(ocode, Lch[b], maxit, layered=layered, want_state=True)
+            assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+            assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+            assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+            assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
+def test_tmm_large_batch_vs_oracle(nb, code, ocode, orc):
+    """256 frames of the reference stream at Eb/N0 = 2.5 dB through both schedules; every frame against the oracle."""
+    cw = np.loadtxt(os.path.join(DATA, "nb", "codeword_bds_gf64.txt"), dtype=np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(2.5, code.rate)
+    rx = nb.AWGNChannel_GPU(seed, sigma, code, torch.from_numpy(cw).cuda(), 256)
+    Lch = nb.Demodulate(code, rx, sigma)
+    Lh = Lch.cpu().numpy()
+    for layered in (False, True):
+        r = nb.Decoding_TMM(code, Lch, 20, layered=layered)
+        torch.cuda.synchronize()
+        out, it, ok = r["DecodeOutput"].cpu().numpy(), r["iter_number"].cpu().numpy(), r["ok"].cpu().numpy()
+        for b in range(0, 256, 3):
+            want = orc.nb_tmm_decode(ocode, Lh[b], 20, layered=layered)
+            assert it[b] == want["it"] and ok[b] == want["ok"] and np.array_equal(out[b], want["out"]), (layered, b)
