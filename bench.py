@@ -43,6 +43,9 @@ WORKLOADS = {
     "J4_L24_Z512": ("J4_L24_Z512_BlockH.txt", 4, 24, 512, 8192, 3.0, 50),
     # GF(64) EMS (BASELINE.json configs[4]): frames per GPU, Eb/N0 dB, maxIT (reference default 20, define.h:35)
     "NB_BDS_GF64": ("BDS.576.288.GF.64.txt", 0, 0, 0, 16384, 3.0, 20),
+    # the reference's other decoder_method values on the same code (define.h:37): 1 trellis min-max, 3 layered trellis min-max
+    "NB_BDS_GF64_TMM": ("BDS.576.288.GF.64.txt", 0, 0, 1, 16384, 3.0, 20),
+    "NB_BDS_GF64_LTMM": ("BDS.576.288.GF.64.txt", 0, 0, 3, 16384, 3.0, 20),
 }
 
 
@@ -129,7 +132,7 @@ def cpu_threads():
     return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
-def nb_cpu_baseline(snr, nframes):
+def nb_cpu_baseline(snr, nframes, method=0):
     """The REFERENCE's own CPU decoder (oracle/_ref/nb_ref, built from /root/reference/myNBLDPC/src/*.cpp;
     single-threaded like the reference's THREAD_NUM 1) on the first frames of the same stream."""
     import subprocess
@@ -138,16 +141,18 @@ def nb_cpu_baseline(snr, nframes):
     if ref is None:
         return None
     nframes = nframes or 300  # ~33 frames/s at 3 dB -> ~10 s
-    out = subprocess.check_output([ref, "time", str(snr), str(nframes)], cwd=os.path.join(ROOT, "data", "nb")).decode()
+    nframes = nframes * (1 if method == 0 else 3)  # the trellis decoders converge in fewer, cheaper iterations
+    out = subprocess.check_output([ref, "time", str(snr), str(nframes), str(method)], cwd=os.path.join(ROOT, "data", "nb")).decode()
     j = json.loads(out.strip().splitlines()[-1])
     return {"value": j["frames_per_s"], "unit": "codewords/s", "cores": 1, "kind": "reference",
-            "sample": "first %d frames of the same seed-173 stream at Eb/N0 %.1f dB, reference Decoding_EMS (maxIT 20, early exit), "
-                      "mean %.2f iterations, %.1f s" % (nframes, snr, j["mean_iters"], j["seconds"])}
+            "sample": "first %d frames of the same seed-173 stream at Eb/N0 %.1f dB, reference %s (maxIT 20, early exit), "
+                      "mean %.2f iterations, %.1f s" % (nframes, snr, {0: "Decoding_EMS", 1: "Decoding_TMM", 3: "Decoding_layered_TMM"}[method],
+                                                         j["mean_iters"], j["seconds"])}
 
 
 def run_nb(args, rank, world, dev, dist):
     from cuda_ldpc_amd import nbldpc as nb
-    name, _, _, _, frames, snr, iters = WORKLOADS[args.workload]
+    name, _, _, method, frames, snr, iters = WORKLOADS[args.workload]
     if args.frames:
         frames = args.frames
     if args.snr is not None:
@@ -172,15 +177,20 @@ def run_nb(args, rank, world, dev, dist):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def decode():
+        if method == 0:
+            return nb.Decoding_EMS(code, Lch, 2, 2, iters, stream=stream)
+        return nb.Decoding_TMM(code, Lch, iters, layered=(method == 3), stream=stream)
+
     for _ in range(args.warmup):
-        nb.Statistic(code, counters, nb.Decoding_EMS(code, Lch, 2, 2, iters, stream=stream), cwd, stream=stream)
+        nb.Statistic(code, counters, decode(), cwd, stream=stream)
     counters.zero_()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)
-        r = nb.Decoding_EMS(code, Lch, 2, 2, iters, stream=stream)
+        r = decode()
         ev[k][1].record(stream)
         nb.Statistic(code, counters, r, cwd, stream=stream)
     tot = counters.clone()
@@ -197,24 +207,26 @@ def run_nb(args, rank, world, dev, dist):
         return
     n_all = frames * world * args.steps
     alg_bytes = (4 * code.N * (code.q - 1) + 4 * code.N) * frames  # L_ch in + symbols out
+    kname = {0: "k_nb_ems<64>", 1: "k_nb_tmm<64, false>", 3: "k_nb_tmm<64, true>"}[method]
+    mname = {0: "GF(64) EMS", 1: "GF(64) trellis min-max", 3: "GF(64) layered trellis min-max"}[method]
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     c = tot.cpu().tolist()
     out = {
-        "metric": "decoded codewords/sec (GF(64) EMS, maxIT %d, per-frame syndrome exit as the reference)" % iters,
+        "metric": "decoded codewords/sec (%s, maxIT %d, per-frame syndrome exit as the reference)" % (mname, iters),
         "value": n_all / elapsed, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "myNBLDPC BDS N576_K288 GF(64) EMS(Nm=2,Nc=2) batch=%d codewords/GPU Eb/N0=%.1fdB" % (frames, snr),
-                   "kernel": "nb_ems<q64> one frame per workgroup", "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
+        "config": {"workload": "myNBLDPC BDS N576_K288 %s batch=%d codewords/GPU Eb/N0=%.1fdB" % ("GF(64) EMS(Nm=2,Nc=2)" if method == 0 else mname, frames, snr),
+                   "kernel": "%s one frame per workgroup" % kname, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("k_nb_ems<64>"), "kernel": "k_nb_ems<64>", "kernel_ms": kern_ms,
-                     "onchip": pmc_onchip("k_nb_ems<64>", kern_ms),
+                     "traffic": pmc_traffic(kname), "kernel": kname, "kernel_ms": kern_ms,
+                     "onchip": pmc_onchip(kname, kern_ms),
                      "algorithmic_bytes_per_launch": alg_bytes},
         "stats": {"frames": n_all, "error_frames": c[0], "symbol_errors": c[1], "FER": c[0] / n_all, "SER": c[1] / n_all / code.N,
                   "mean_iterations": c[2] / n_all},
     }
     if world == 1 and not args.no_cpu_baseline:
-        cb = nb_cpu_baseline(snr, args.cpu_frames)
+        cb = nb_cpu_baseline(snr, args.cpu_frames, method)
         if cb:
             out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)

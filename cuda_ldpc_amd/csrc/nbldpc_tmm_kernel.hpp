@@ -25,6 +25,10 @@
 
 #include "nbldpc_kernel.hpp"
 
+#ifndef TMM_ABLATE
+#define TMM_ABLATE 0 // experiments only (timing, wrong results): 1 no ConstructConf walk, 2 no check rows at all
+#endif
+
 namespace cldpc {
 
 constexpr int kTmmThreads = 1024;
@@ -64,7 +68,7 @@ __device__ __forceinline__ float nb_wave_min(float v)
 
 __host__ __device__ inline size_t tmm_lds_bytes(int N, int M, int q, int dv, int dc, bool layered)
 {
-    size_t fl = (size_t)N * q + (size_t)M * dc * q + (layered ? 0 : (size_t)N * dv * q) + (size_t)(kTmmThreads / 64) * 64 * 2 + N + 4;
+    size_t fl = (((size_t)N * q + (size_t)M * dc * q + (layered ? 0 : (size_t)N * dv * q) + 127) & ~(size_t)127) + (size_t)(kTmmThreads / 64) * 64 * 2 + N + 4;
     size_t tb = (size_t)N + (size_t)N * dv + (size_t)M + 4 * (size_t)M * dc + (size_t)M + 64 + 2;
     return fl * sizeof(float) + (size_t)q * q + tb * sizeof(unsigned short);
 }
@@ -80,7 +84,7 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
     float *LLR = lds;                               // [N][q]
     float *C2V = LLR + N * q;                       // [TC][q]
     float *V2C = C2V + TC * q;                      // [NE][q] (flooding only)
-    float *PR = V2C + (LAYERED ? 0 : NE * q);       // [nwaves][64][2]  (Min1, Col) pairs of the row a wave works on
+    float *PR = lds + (((LLR - lds) + N * q + TC * q + (LAYERED ? 0 : NE * q) + 127) & ~127); // [nwaves][64][2] (Min1, Col) pairs, 512-byte aligned
     int *outs = reinterpret_cast<int *>(PR + nwaves * 128); // [N]
     int *flag = outs + N;                           // [4]
     unsigned char *mulb = reinterpret_cast<unsigned char *>(flag + 4); // [q][q]
@@ -165,20 +169,51 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
             pr[lane * 2] = M1;
             pr[lane * 2 + 1] = __int_as_float(Col);
         }
-        float I = M1, E = M2;
+        // The reference's two branches (:797-810) take the larger of (Min1[j], Min1[k]) when the two differ, their columns
+        // differ and it beats I.  Per step and lane: one permuted read, the candidate, three compares whose masks meet
+        // on the scalar unit, two selects; which step won last is all that has to be remembered (path and E follow).
+        // deltaU = v - min >= +0 and never -0 or NaN for finite inputs, so the walk compares the BIT PATTERNS as unsigned
+        // integers (same order, no canonicalisation instructions); the (Min1, Col) array of a wave is 512-byte aligned, so the
+        // permuted address is one XOR with a literal.
+        unsigned Ib = __float_as_uint(M1);
+        int jb = -1;
+        unsigned long long upd = 0; // lanes whose I was replaced at least once
+        const unsigned prb = (unsigned)(uintptr_t)pr; // LDS byte address of this wave's pairs (low 9 bits zero)
+        const unsigned xaddr = prb + (unsigned)lane * 8u;
+        typedef unsigned tmm_u2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const tmm_u2 lds_u2;
+        constexpr int JB = 8; // steps whose permuted reads are in flight together
+#pragma unroll
+        for (int j0 = 0; j0 < ((TMM_ABLATE & 1) ? 0 : q); j0 += JB) {
+            tmm_u2 pjv[JB], pkv[JB];
+#pragma unroll
+            for (int u = 0; u < JB; u++) {
+                pjv[u] = *reinterpret_cast<lds_u2 *>(prb + 8u * (j0 + u));
+                pkv[u] = *reinterpret_cast<lds_u2 *>(xaddr ^ (8u * (j0 + u)));
+            }
+#pragma unroll
+            for (int u = 0; u < JB; u++) {
+                const int j = j0 + u;
+                const unsigned c = max(pjv[u].x, pkv[u].x);
+                const unsigned long long t = __builtin_amdgcn_ballot_w64(pjv[u].y != pkv[u].y) & __builtin_amdgcn_ballot_w64(pjv[u].x != pkv[u].x) &
+                                             __builtin_amdgcn_ballot_w64(c < Ib) & ~(1ull << j);
+                const bool tk = __builtin_amdgcn_inverse_ballot_w64(t);
+                Ib = tk ? c : Ib;
+                jb = tk ? j : jb;
+                upd |= t;
+                asm volatile("" : "+v"(jb)); // select now: otherwise all 64 masks are kept (and spilled) for a later chain
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float I = __uint_as_float(Ib);
+        const bool any = __builtin_amdgcn_inverse_ballot_w64(upd);
+        const float E = any ? M1 : M2;
         int P0 = Col, P1 = Col;
-#pragma unroll 8
-        for (int j = 0; j < q; j++) {
-            const float2 pj = *reinterpret_cast<const float2 *>(pr + 2 * j);
-            const float2 pk = *reinterpret_cast<const float2 *>(pr + 2 * ((lane ^ j) & (q - 1)));
-            const int cj = __float_as_int(pj.y), ck = __float_as_int(pk.y);
-            const bool cond = (cj != ck) && (lane != j);
-            const bool t1 = cond && pj.x > pk.x && pj.x < I;
-            const bool t2 = cond && pj.x < pk.x && pk.x < I;
-            I = t1 ? pj.x : (t2 ? pk.x : I);
-            P0 = (t1 || t2) ? cj : P0;
-            P1 = (t1 || t2) ? ck : P1;
-            E = (t1 || t2) ? M1 : E;
+        if (upd) { // wave-uniform
+            const int jbc = max(jb, 0);
+            const int c0 = __float_as_int(pr[2 * jbc + 1]), c1 = __float_as_int(pr[2 * ((lane ^ jbc) & (q - 1)) + 1]);
+            P0 = any ? c0 : Col;
+            P1 = any ? c1 : Col;
         }
         // outputs (:506-530)
 #pragma unroll
@@ -236,7 +271,7 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
         }
         // ---- check rows
         if (!LAYERED) {
-            for (int row = wave; row < M; row += nwaves) do_row(row);
+            for (int row = wave; row < ((TMM_ABLATE & 2) ? 0 : M); row += nwaves) do_row(row);
             __syncthreads();
         } else {
             for (int lv = 0; lv < a.levels; lv++) {
