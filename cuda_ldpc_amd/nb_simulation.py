@@ -41,9 +41,10 @@ class NBSim:
 
 
 def Simulation_GPU(code, seed, sigma, SIM, CodeWord_sym, EMS_Nm=2, EMS_Nc=2, maxIT=20, batch=1024, leastErrorFrames=50,
-                   leastTestFrames=1000, max_frames=None, device=None, device_channel=False):
+                   leastTestFrames=1000, max_frames=None, device=None, device_channel=False, decoder_method=0):
     """One Eb/N0 point. `seed` (int32[3]) advances exactly as far as the reference would have drawn.
-    device_channel: generate the noise on the GPU (same uniforms, device libm) instead of the host, frame by frame."""
+    device_channel: generate the noise on the GPU (same uniforms, device libm) instead of the host, frame by frame.
+    decoder_method (define.h:37, Simulation.cpp:54-70): 0 EMS, 1 trellis min-max, 2 log-QSPA = EMS(q, dc-1), 3 layered TMM."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     cw = np.ascontiguousarray(CodeWord_sym, np.int32)
     cw_dev = torch.from_numpy(cw).to(device)
@@ -60,7 +61,12 @@ def Simulation_GPU(code, seed, sigma, SIM, CodeWord_sym, EMS_Nm=2, EMS_Nc=2, max
                 rx[b] = nb.AWGNChannel_CPU(seed, sigma, code, cw)
             rxt = torch.from_numpy(rx).to(device)
         Lch = nb.Demodulate(code, rxt, sigma)
-        r = nb.Decoding_EMS(code, Lch, EMS_Nm, EMS_Nc, maxIT)
+        if decoder_method == 0:
+            r = nb.Decoding_EMS(code, Lch, EMS_Nm, EMS_Nc, maxIT)
+        elif decoder_method == 2:
+            r = nb.Decoding_EMS(code, Lch, code.q, code.dc - 1, maxIT)  # Simulation.cpp:63-66
+        else:
+            r = nb.Decoding_TMM(code, Lch, maxIT, layered=(decoder_method == 3))
         errs = (r["DecodeOutput"] != cw_dev[None, :]).sum(dim=1).cpu().numpy()
         its = r["iter_number"].cpu().numpy()
         for b in range(batch):  # account in stream order; stop where the reference's while-condition fails

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--max-batches", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--fixed", action="store_true", help="fixed iteration count instead of the reference's batch-global early exit")
+    ap.add_argument("--method", type=int, default=0, choices=[0, 1, 2, 3], help="NB decoder_method (define.h:37): 0 EMS, 1 TMM, 2 log-QSPA, 3 layered TMM")
     ap.add_argument("--device-channel", action="store_true", help="generate the AWGN samples on the GPU (same RNG draws, device libm)")
     ap.add_argument("--as-written", action="store_true", help="decode on the reference's Transform_H table as written (SURVEY F3)")
     args = ap.parse_args()
@@ -70,11 +71,12 @@ def main():
         mul, _, _ = nb.GFInitial(64, os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
         code = nb.NBCode(os.path.join(nbd, "BDS.576.288.GF.64.txt"), mul)
         cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
-        print("# BDS.576.288.GF.64 N=%d symbols GF(%d), EMS(2,2), maxIT=%d" % (code.N, code.q, args.iters or 20))
+        print("# BDS.576.288.GF.64 N=%d symbols GF(%d), %s, maxIT=%d" % (code.N, code.q, ["EMS(2,2)", "trellis min-max", "log-QSPA = EMS(q,dc-1)", "layered trellis min-max"][args.method], args.iters or 20))
         print("# SNR      NTF   NEF         FER         BER  AverIT")
         nbatch = args.batch if args.device_channel else min(args.batch, 1024)  # the host channel is serial: keep its batches small
         sweep(code, cw, args.start, args.stop, args.step, maxIT=args.iters or 20, batch=nbatch,
-              max_frames=None if args.max_batches is None else args.max_batches * nbatch, device_channel=args.device_channel)
+              max_frames=None if args.max_batches is None else args.max_batches * nbatch, device_channel=args.device_channel,
+              decoder_method=args.method)
     if world > 1:
         dist.destroy_process_group()
 
