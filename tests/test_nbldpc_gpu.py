@@ -275,3 +275,20 @@ def test_tmm_large_batch_vs_oracle(nb, code, ocode, orc):
         for b in range(0, 256, 3):
             want = orc.nb_tmm_decode(ocode, Lh[b], 20, layered=layered)
             assert it[b] == want["it"] and ok[b] == want["ok"] and np.array_equal(out[b], want["out"]), (layered, b)
+
+
+def test_log_qspa_is_ems_q_dcm1(nb, code, ocode, orc):
+    """decoder_method 2 (Simulation.cpp:63-66): Decoding_EMS(GFQ, maxdc - 1) -- every configuration of every row."""
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(3.0, code.rate)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, cw) for _ in range(2)])
+    Lch = nb.Demodulate(code, torch.from_numpy(rx).cuda(), sigma)
+    r = nb.Decoding_EMS(code, Lch, code.q, code.dc - 1, 2, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(2):
+        want = orc.nb_ems_decode(ocode, orc.nb_demodulate(ocode, rx[b], sigma), code.q, code.dc - 1, 2, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
