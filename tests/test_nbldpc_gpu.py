@@ -292,3 +292,70 @@ def test_log_qspa_is_ems_q_dcm1(nb, code, ocode, orc):
         assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
         assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
         assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
+def _synthetic_code(tmp_path, nb, q, poly, N, dv, dc, seed):
+    """A random (dv, dc)-regular GF(q) code written in the reference's matrix and GF-table formats (Appendix C), so that the
+    product reader, the oracle reader and both decoders see the same files.  The reference ships GF(64) only; this
+    exercises the q = 16 / 32 instantiations (lanes beyond q idle) and irregular slot orders."""
+    rng = np.random.default_rng(seed)
+    M = N * dv // dc
+    while True:  # configuration-model bipartite graph without parallel edges
+        stubs = np.repeat(np.arange(N), dv)
+        rng.shuffle(stubs)
+        rows = stubs.reshape(M, dc)
+        if all(len(set(r)) == dc for r in rows):
+            break
+    gf = rng.integers(1, q, size=(M, dc))
+    vn_edges = [[] for _ in range(N)]
+    for r in range(M):
+        for t in range(dc):
+            vn_edges[rows[r, t]].append((r, gf[r, t]))
+    mpath, gpath = str(tmp_path / ("code%d.txt" % q)), str(tmp_path / ("gf%d.txt" % q))
+    with open(mpath, "w") as f:
+        f.write("%d %d %d\n%d %d\n" % (N, M, q, dv, dc))
+        f.write(" ".join([str(dv)] * N) + "\n" + " ".join([str(dc)] * M) + "\n")
+        for i in range(N):
+            f.write(" ".join("%d %d" % (r + 1, h) for r, h in vn_edges[i]) + "\n")
+        for r in range(M):
+            f.write(" ".join("%d %d" % (rows[r, t] + 1, gf[r, t]) for t in range(dc)) + "\n")
+    mul, add, inv = nb.GFInitial(q, primitive_poly=poly)
+    with open(gpath, "w") as f:
+        f.write("GF(%d) with Primitive Polynomial: %d.\nMultiply Table:\n" % (q, poly))
+        for a in range(q):
+            f.write(" ".join(str(int(x)) for x in mul[a]) + "\n")
+        f.write("Add Table:\n")
+        for a in range(q):
+            f.write(" ".join(str(int(x)) for x in add[a]) + "\n")
+        f.write("Inverse Table:\n" + " ".join(str(int(x)) for x in inv) + "\n")
+    return mpath, gpath
+
+
+@pytest.mark.parametrize("q,poly,N", [(16, 19, 48), (32, 37, 60)])
+def test_other_fields_synthetic_codes(nb, orc, tmp_path, q, poly, N):
+    mpath, gpath = _synthetic_code(tmp_path, nb, q, poly, N, 2, 4, seed=q)
+    mul, _, _ = nb.GFInitial(q, gpath)
+    code = nb.NBCode(mpath, mul)
+    ocode = orc.NBCode(mpath, gpath)
+    assert (code.N, code.M, code.q) == (N, N // 2, q)
+    rng = np.random.default_rng(q + 1)
+    B = 6
+    Lch = (rng.standard_normal((B, N, q - 1)) * 2.0).astype(np.float32)
+    Lch[0] = np.round(Lch[0])  # ties
+    Lt = torch.from_numpy(Lch).cuda()
+    r = nb.Decoding_EMS(code, Lt, 2, 2, 4, want_state=True)
+    t1 = nb.Decoding_TMM(code, Lt, 4, layered=False, want_state=True)
+    t3 = nb.Decoding_TMM(code, Lt, 4, layered=True, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        want = orc.nb_ems_decode(ocode, Lch[b], 2, 2, 4, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+        for got, layered in ((t1, False), (t3, True)):
+            want = orc.nb_tmm_decode(ocode, Lch[b], 4, layered=layered, want_state=True)
+            assert int(got["iter_number"][b]) == want["it"] and int(got["ok"][b]) == want["ok"], (layered, b)
+            assert np.array_equal(got["DecodeOutput"][b].cpu().numpy(), want["out"])
+            assert np.array_equal(got["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+            assert np.array_equal(got["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
