@@ -138,6 +138,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     const int rbase = (g * WC * Z + t) * MSG;          // + (rr*G*WC + pp)*Z*MSG as immediate offsets
     const int sbase = (GM::Sslot + g * Z + t) * MSG;   // + cc*G*Z*MSG
     unsigned saddr[RPT][(WC + 1) / 2];                 // S slots of the row's neighbours, packed 2 x 16 bit
+    constexpr bool UNPACKED = RPT * WC <= 16;          // few enough to keep as byte addresses (saves 2 VALU per edge and iteration)
+    int saddr_u[UNPACKED ? RPT : 1][UNPACKED ? WC : 1];
     // All table gathers are issued unconditionally (index clamped into the row / column) and only then
     // consumed: predicated loads would be waited for one by one, ~0.4 us each under load.
     int e0v[RPT], wrv[RPT];
@@ -161,6 +163,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             const int slot = (pp < wrv[rr]) ? GM::Sslot + ed[pp].col * Z + c : GM::inf_slot;
             if (pp & 1) saddr[rr][pp / 2] |= (unsigned)slot << 16;
             else saddr[rr][pp / 2] = (unsigned)slot;
+            if (UNPACKED) saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0] = slot * MSG;
             const float zero[NF] = {};
             lds_st<NF>(lds, rbase + (rr * G * WC + pp) * Z * MSG, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
         }
@@ -248,7 +251,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
-            for (int i = 0; i < (WC + 1) / 2; i++) asm volatile("" : "+v"(saddr[rr][i]));
+            for (int i = 0; i < (WC + 1) / 2; i++)
+                if (!UNPACKED) asm volatile("" : "+v"(saddr[rr][i]));
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
@@ -273,7 +277,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 for (int i = 0; i < CH; i++) {
                     const int pp = p0 + i;
                     const unsigned pk = saddr[rr][pp / 2];
-                    if (!(QC_ABLATE & 2)) lds_ld<NF>(Sv[i], lds, (int)((pp & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
+                    if (UNPACKED) lds_ld<NF>(Sv[i], lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
+                    else if (!(QC_ABLATE & 2)) lds_ld<NF>(Sv[i], lds, (int)((pp & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
                     else { for (int v = 0; v < NF; v++) Sv[i][v] = __uint_as_float(pk + pp + it); }
                     if (!(QC_ABLATE & 8)) lds_ld<NF>(Rv[i], lds, rbase + (rr * G * WC + pp) * Z * MSG);
                     else { for (int v = 0; v < NF; v++) Rv[i][v] = __uint_as_float(pk * 3 + pp); }
