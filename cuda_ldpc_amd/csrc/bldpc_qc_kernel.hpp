@@ -266,6 +266,11 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         for (int rr = 0; rr < RPT; rr++) {
             // CH: edges whose S and R reads are in flight together (bounds VGPR use)
             constexpr int CH = (WC % 5 == 0) ? 5 : ((WC % 4 == 0) ? 4 : ((WC % 7 == 0) ? 7 : WC));
+            // When Z is a whole number of waves the row (hence its weight) is wave-uniform: the last two slots, the ones
+            // that may be padding, are skipped by a scalar branch instead of being computed on the +inf slot.
+            constexpr bool ROWU = (Z % 64 == 0);
+            const int wu = ROWU ? __builtin_amdgcn_readfirstlane(wrv[rr]) : WC;
+            auto slot_on = [&](int pp) -> bool { return !ROWU || pp < WC - 2 || pp < wu; };
             float Q[WC][NF];
             CnAcc acc[NF];
 #pragma unroll
@@ -277,6 +282,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 for (int i = 0; i < CH; i++) {
                     const int pp = p0 + i;
                     const unsigned pk = saddr[rr][pp / 2];
+                    if (!slot_on(pp)) continue;
                     if (UNPACKED) lds_ld<NF>(Sv[i], lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
                     else if (!(QC_ABLATE & 2)) lds_ld<NF>(Sv[i], lds, (int)((pp & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
                     else { for (int v = 0; v < NF; v++) Sv[i][v] = __uint_as_float(pk + pp + it); }
@@ -285,6 +291,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 }
 #pragma unroll
                 for (int i = 0; i < CH; i++) {
+                    if (!slot_on(p0 + i)) continue;
 #pragma unroll
                     for (int v = 0; v < NF; v++) {
                         Q[p0 + i][v] = Sv[i][v] - Rv[i][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
@@ -298,6 +305,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             for (int v = 0; v < NF; v++) key[v] = acc[v].key();
 #pragma unroll
             for (int pp = 0; pp < WC; pp++) {
+                if (!slot_on(pp)) continue;
                 float Rn[NF];
 #pragma unroll
                 for (int v = 0; v < NF; v++) Rn[v] = cn_out(Q[pp][v], acc[v].m2, key[v]);
