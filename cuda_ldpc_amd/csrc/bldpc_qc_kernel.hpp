@@ -644,12 +644,17 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     const int t0 = tid - g * U;
     const bool lane_on = t0 < Z;      // the surplus lanes of the padded group idle
     const int t = lane_on ? t0 : 0;   // ... on valid addresses
-    const int off_w2 = M * 8, off_S = M * 12;
+    // check states 0 .. M-1, then Z states that stay zero (R = +0: what the padding entries of a column's edge list add)
+    const int off_w2 = (M + Z) * 8, off_S = (M + Z) * 12;
     int *lds_flag = reinterpret_cast<int *>(lds + off_S + (L + 1) * Z * 4);
     const int f = wg; // one frame per workgroup
+    // per-edge tables, wave-uniform; read through the constant address space: scalar loads whatever else the kernel stores
+    typedef __attribute__((address_space(4))) const unsigned qcc_cu32;
+    const qcc_cu32 *cmeta = (const qcc_cu32 *)a.cn_meta; // [J][WCS] row slots, then [J] row weights
+    const qcc_cu32 *vmeta = (const qcc_cu32 *)a.vn_meta; // [L][WVS] column edges, padded to a multiple of 4 with zero-state entries
 
     // ---- prologue -----------------------------------------------------------------------------------------
-    for (int j = g; j < J; j += G)
+    for (int j = g; j < J + 1; j += G)
         if (lane_on) {
             const float zero2[2] = {0.0f, 0.0f}; // min1 = min2 = 0, no signs: every R starts as +0 (LDPC_Decoder.cu:82)
             lds_st<2>(lds, (j * Z + t) * 8, zero2);
@@ -678,18 +683,23 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
             const int l = g + cc * G;
             if (l < L) { // wave-uniform
                 float S = 0.0f;
-                const unsigned *vm = a.vn_meta + l * a.WVS;
-#pragma unroll 4
-                for (int k = 0; k < wcol[cc]; k++) {
-                    const unsigned m = vm[k]; // scalar load
-                    const int j = m & 63, pos = (m >> 6) & 31, sh = m >> 11;
-                    int r = t - sh;
-                    r = (r < 0) ? r + Z : r;
-                    const int sidx = j * Z + r;
-                    float mm[2], w2f[1];
-                    lds_ld<2>(mm, lds, sidx * 8);
-                    lds_ld<1>(w2f, lds, off_w2 + sidx * 4);
-                    S += qcc_recon(mm[0], mm[1], f2u(w2f[0]), pos); // ascending block row = the reference's edge order
+                const qcc_cu32 *vm = vmeta + l * a.WVS;
+                for (int k0 = 0; k0 < wcol[cc]; k0 += 4) { // four edges per round, straight-line (the list is padded)
+                    float mm[4][2], w2f[4][1];
+                    int pos[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned m = vm[k0 + i]; // scalar load
+                        const int j = m & 63, sh = m >> 11;
+                        pos[i] = (m >> 6) & 31;
+                        int r = t - sh;
+                        r = (r < 0) ? r + Z : r;
+                        const int sidx = j * Z + r;
+                        lds_ld<2>(mm[i], lds, sidx * 8);
+                        lds_ld<1>(w2f[i], lds, off_w2 + sidx * 4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) S += qcc_recon(mm[i][0], mm[i][1], f2u(w2f[i][0]), pos[i]); // ascending block row = the reference's edge order
                 }
                 S += yreg[cc];
                 if (lane_on) {
@@ -724,31 +734,37 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
             lds_ld<2>(pm, lds, sidx * 8);
             lds_ld<1>(pw, lds, off_w2 + sidx * 4);
             const unsigned pw2 = f2u(pw[0]);
-            const unsigned *cm = a.cn_meta + j * WCS;
-            const int w = a.rowptr[j + 1] - a.rowptr[j];
-            float Sv[WCS];
-#pragma unroll
-            for (int p = 0; p < WCS; p++) {
-                const unsigned m = cm[p]; // scalar load; padding slots point at the +inf column with shift 0
-                const int col = m & 255, sh = m >> 8;
-                int c = t + sh;
-                c = (c >= Z) ? c - Z : c;
-                float sv[1];
-                lds_ld<1>(sv, lds, off_S + (col * Z + c) * 4);
-                Sv[p] = sv[0];
-            }
+            const qcc_cu32 *cm = cmeta + j * WCS;
+            const int w = (int)cmeta[J * WCS + j]; // row weight (scalar load)
             float m1 = __builtin_inff(), m2 = __builtin_inff();
             unsigned signs = 0;
             int idx = 0;
+            constexpr int CHK = 4; // slots per round; rounds beyond the row's weight are skipped by a scalar branch
 #pragma unroll
-            for (int p = 0; p < WCS; p++) {
-                const float q = Sv[p] - qcc_recon(pm[0], pm[1], pw2, p); // Q = S - R  (LDPC_Decoder.cu:206-209)
-                const float aq = __builtin_fabsf(q);
-                idx = (aq < m1) ? p : idx;                       // first edge holding the minimum (:298-305)
-                m2 = __builtin_amdgcn_fmed3f(m1, m2, aq);
-                m1 = __builtin_fminf(m1, aq);
-                signs |= (f2u(q) >> 31) << p;
-            }
+            for (int p0 = 0; p0 < WCS; p0 += CHK)
+                if (p0 < w) {
+                    float Sv[CHK];
+#pragma unroll
+                    for (int i = 0; i < CHK; i++) {
+                        const unsigned m = cm[p0 + i]; // scalar load; padding slots point at the +inf column with shift 0
+                        const int col = m & 255, sh = m >> 8;
+                        int c = t + sh;
+                        c = (c >= Z) ? c - Z : c;
+                        float sv[1];
+                        lds_ld<1>(sv, lds, off_S + (col * Z + c) * 4);
+                        Sv[i] = sv[0];
+                    }
+#pragma unroll
+                    for (int i = 0; i < CHK; i++) {
+                        const int p = p0 + i;
+                        const float q = Sv[i] - qcc_recon(pm[0], pm[1], pw2, p); // Q = S - R  (LDPC_Decoder.cu:206-209)
+                        const float aq = __builtin_fabsf(q);
+                        idx = (aq < m1) ? p : idx;                       // first edge holding the minimum (:298-305)
+                        m2 = __builtin_amdgcn_fmed3f(m1, m2, aq);
+                        m1 = __builtin_fminf(m1, aq);
+                        signs |= (f2u(q) >> 31) << p;
+                    }
+                }
             // R_p = Sign[25]*Sign[p] * magnitude: output sign bit p = parity of all signs XOR sign p
             if (__builtin_popcount(signs) & 1) signs ^= (1u << w) - 1u;
             if (lane_on) {
@@ -920,8 +936,8 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.MINW > Wcmin || L > 255 || Z > 2047 || lds > kLdsBytes) continue;
             q->lds_bytes = (int)lds;
         } else if (v.U) { // compressed-state kernel: geometry-generic
-            const size_t lds = (size_t)J * Z * 12 + (size_t)(L + 1) * Z * 4 + 16;
-            if (v.Z != Z || (L + v.G - 1) / v.G > v.CPT || v.WC < Wc || Wv > 31 || J > 63 || L > 254 || Z > 2047 || lds > kLdsBytes) continue;
+            const size_t lds = (size_t)(J + 1) * Z * 12 + (size_t)(L + 1) * Z * 4 + 16;
+            if (v.Z != Z || (L + v.G - 1) / v.G > v.CPT || v.WC < Wc || Wv > 28 || J > 62 || L > 254 || Z > 2047 || lds > kLdsBytes) continue;
             q->lds_bytes = (int)lds;
         } else {
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.WV < Wv) continue;
@@ -959,15 +975,18 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
     }
     if (v.U) { // meta tables of the compressed-state kernel
-        q->WVS = Wv;
-        std::vector<unsigned> cm((size_t)J * v.WC, qcc_cn_meta(L, 0)), vm((size_t)L * Wv, 0u);
+        const int WVS = (Wv + 3) / 4 * 4; // column edge lists padded to whole rounds of 4 with entries of the zero state (row J)
+        q->WVS = WVS;
+        std::vector<unsigned> cm((size_t)J * v.WC + J, qcc_cn_meta(L, 0)), vm((size_t)L * WVS, qcc_vn_meta(J, 0, 0));
         std::vector<int> fillc(L, 0);
-        for (int j = 0; j < J; j++)
+        for (int j = 0; j < J; j++) {
             for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
                 const int pos = e - rowptr[j], l = cn[e].col;
                 cm[(size_t)j * v.WC + pos] = qcc_cn_meta(l, cn[e].shift);
-                vm[(size_t)l * Wv + fillc[l]++] = qcc_vn_meta(j, pos, cn[e].shift); // ascending j = the reference's edge order
+                vm[(size_t)l * WVS + fillc[l]++] = qcc_vn_meta(j, pos, cn[e].shift); // ascending j = the reference's edge order
             }
+            cm[(size_t)J * v.WC + j] = (unsigned)(rowptr[j + 1] - rowptr[j]); // row weights behind the slots
+        }
         CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(hipMalloc((void **)&q->d_vn_meta, vm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
