@@ -359,3 +359,33 @@ def test_other_fields_synthetic_codes(nb, orc, tmp_path, q, poly, N):
             assert np.array_equal(got["DecodeOutput"][b].cpu().numpy(), want["out"])
             assert np.array_equal(got["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
             assert np.array_equal(got["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
+@pytest.mark.parametrize("method,tag", [(0, "nb_ref"), (1, "nb_ref_tmm"), (3, "nb_ref_ltmm")])
+def test_reference_signature_shim_cpp_harness(nb, code, orc, tmp_path, method, tag):
+    """A C++ harness in the reference's calling style (pointer-rich VN[] / CN[], one frame per call) drives
+    Decoding_EMS / Decoding_TMM / Decoding_layered_TMM with the reference's signatures (shim/nbldpc_ref_shim.*):
+    return flags, iteration counts and the hashes of DecodeOutput, VN[].LLR and CN[].L_c2v equal the reference's own."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from cuda_ldpc_amd._lib import SO_PATH
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    exe = str(tmp_path / "nb_ref_style_harness")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "shim"),
+                           os.path.join(root, "tests", "cpp", "nb_ref_style_harness.cpp"), os.path.join(root, "shim", "nbldpc_ref_shim.hip"),
+                           "-o", exe, "-L", os.path.dirname(SO_PATH), "-lcuda_ldpc_amd", "-Wl,-rpath," + os.path.dirname(SO_PATH), "-pthread"])
+    g = np.load(os.path.join(GOLDEN, "%s_3dB.npz" % tag))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"])).cpu().numpy()
+    lpath = str(tmp_path / "lch.bin")
+    Lch.tofile(lpath)
+    frames = Lch.shape[0]
+    out = subprocess.check_output([exe, os.path.join(NB, "BDS.576.288.GF.64.txt"), os.path.join(NB, "GF", "Arith.Table.GF.64.txt"), lpath,
+                                   str(frames), str(method)]).decode().strip().splitlines()
+    assert len(out) == frames, out
+    for fr, line in enumerate(out):
+        want = "frame %d ok=%d it=%d out=%08x LLR=%08x c2v=%08x" % (fr, int(g["ok"][fr]), int(g["it"][fr]), orc.fold_hash(g["out"][fr]),
+                                                                    int(g["LLR_hash"][fr]), int(g["c2v_hash"][fr]))
+        assert line == want, (line, want)
