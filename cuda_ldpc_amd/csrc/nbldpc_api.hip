@@ -134,7 +134,7 @@ static NbKernel nb_kernel(int q, int dv)
 
 static size_t nb_lds_bytes(int N, int M, int q, int dv, int dc)
 {
-    return ((size_t)N * dv * nb_pair_stride(q) + (size_t)q * (M * dc + 1) + N + 4) * sizeof(float) + (size_t)q * q +
+    return ((size_t)N * dv * nb_pair_stride(q) + (size_t)(q + 1) * M * dc + N + 4) * sizeof(float) + (size_t)q * q +
            ((size_t)N + 2 * (size_t)N * dv + (size_t)M + 3 * (size_t)M * dc + 2) * sizeof(unsigned short); // graph tables
 }
 

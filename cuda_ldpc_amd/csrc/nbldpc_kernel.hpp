@@ -6,9 +6,10 @@
 // reference's depth-first order.  That order does not depend on the data, so each (check row, edge)
 // thread executes a fixed straight-line program over its neighbours' sorted messages.
 //
-// LDS (one frame):   pairs[NE][q] (float value, int premultiplied symbol), padded per edge against
-//                    bank conflicts;  E[q][TC] the per-(row,edge) max arrays (EMS_L_c2v), thread-fastest
-//                    so that each lane owns one bank;  the GF multiplication table as bytes.
+// LDS (one frame):   pairs[NE][q] (float value, int premultiplied symbol as a byte offset), padded per edge
+//                    against bank conflicts;  E[M*dc][q+1] the per-(row,edge) max arrays (EMS_L_c2v), one per check
+//                    thread with an odd stride (the entry of a leaf is base + (prefix ^ symbol): one v_xad_u32);
+//                    the GF multiplication table as bytes.
 // Phases per iteration (LDPC_Decoder.cpp:199-313):
 //   A  one wave per variable node, lane k <-> vector element k: c2v from E (the double division of
 //      :309), LLR = L_ch + sum c2v (:202-214), hard decision (:71-91), v2c = LLR - c2v (:241-251)
@@ -140,12 +141,12 @@ template <int K, int W> __device__ __forceinline__ void nb_bitonic_sort(uint32_t
 template <int NACT> struct NbCn {
     int pb[NACT];                   // float index of each active neighbour's sorted pairs
     float v0[NACT], v1[NACT];       // its two largest values   (sort_L_v2c[..][0..1])
-    int m0[NACT], m1[NACT];         // and their premultiplied symbols
+    int m0[NACT], m1[NACT];         // and their premultiplied symbols, as byte offsets (4 * symbol) into the thread's max array
     float s;                        // sumNonLLR, carried by reference through the walk
-    float *E;                       // &E[0*TC + thr]
+    char *E;                        // this thread's max array (EMS_L_c2v of its (row, edge)): q + 1 floats, entry of symbol x at byte 4x
     const float *pairs;
-    int TC;
 };
+__device__ __forceinline__ float &nb_e(char *E, int sym4) { return *reinterpret_cast<float *>(E + sym4); }
 
 // Sub-walk entered with diff == 1 (one deviation already spent) at depth D: exactly one leaf (all
 // remaining positions at k = 0), then on the way back every position tries k = 1, exceeds Nc = 1
@@ -194,7 +195,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 c.s = c.s + v[i];
-                c.E[__mul24(symbase ^ m[i], c.TC)] = c.s;
+                nb_e(c.E, symbase ^ m[i]) = c.s; // the XOR and the add to the base are one v_xad_u32
                 c.s = c.s - v[i];
             }
         }
@@ -216,7 +217,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 v[i] = pr[i].x;
-                sy[i] = __mul24(sfx ^ __float_as_int(pr[i].y), c.TC); // v_mul_u32_u24: full rate (v_mul_lo_u32 is not)
+                sy[i] = sfx ^ __float_as_int(pr[i].y); // byte offset of the leaf's symbol
             }
             {   // the next batch's pairs (the last round re-reads its own: no branch in the loop)
                 const int kn = (k0 + CH < Q) ? k0 + CH : k0;
@@ -224,7 +225,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
                 for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (kn + i));
             }
 #pragma unroll
-            for (int i = 0; i < CH; i++) ev[i] = c.E[sy[i]];
+            for (int i = 0; i < CH; i++) ev[i] = nb_e(c.E, sy[i]);
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 int unused;
@@ -233,7 +234,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
                 c.s = c.s - v[i];
             }
 #pragma unroll
-            for (int i = 0; i < CH; i++) c.E[sy[i]] = (sl[i] > ev[i]) ? sl[i] : ev[i]; // :322-325, as a select: no exec juggling
+            for (int i = 0; i < CH; i++) nb_e(c.E, sy[i]) = (sl[i] > ev[i]) ? sl[i] : ev[i]; // :322-325, as a select: no exec juggling
         }
     }
 }
@@ -242,8 +243,8 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 template <int D, int NACT> __device__ void nb_conf(NbCn<NACT> &c, int symbase, int diff, int Nm, int Nc)
 {
     if constexpr (D == NACT) {
-        float *e = c.E + symbase * c.TC;
-        if (c.s > *e) *e = c.s;
+        float &e = nb_e(c.E, symbase);
+        if (c.s > e) e = c.s;
     } else {
         for (int k = 0; k < Nm; k++) {
             float v;
@@ -266,13 +267,12 @@ template <int D, int NACT> __device__ void nb_conf(NbCn<NACT> &c, int symbase, i
 }
 
 template <int W, int Q>
-__device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, const float *pairs, float *E, int TC, int row, int e, int thr)
+__device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, const float *pairs, float *E, int QP, int row, int e, int thr)
 {
     constexpr int NACT = W - 1;
     NbCn<NACT> c;
-    c.E = E + thr;
+    c.E = reinterpret_cast<char *>(E + thr * QP);
     c.pairs = pairs;
-    c.TC = TC;
     const int PST = nb_pair_stride(a.q);
 #pragma unroll
     for (int i = 0; i < NACT; i++) {
@@ -301,10 +301,11 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
     constexpr int q = Q; // == a.q (the host picks the instantiation)
     const int N = a.N, M = a.M, dv = a.dv, dc = a.dc;
     const int NE = N * dv, TC = M * dc, PST = nb_pair_stride(q);
-    const int TCP = TC + 1; // E row stride: odd, so a variable node reading one thread's column across symbols spreads over the banks
+    constexpr int QP = q + 1; // E is [M*dc][q + 1]: one max array per (row, edge) thread, odd stride: lanes that walk different arrays
+                              // and lanes that read one array across symbols both spread over the banks
     float *pairs = lds;                    // [NE][PST]
     float *E = pairs + NE * PST;           // [q][TC]
-    int *outs = reinterpret_cast<int *>(E + q * TCP);  // [N]
+    int *outs = reinterpret_cast<int *>(E + TC * QP);  // [N]
     int *flag = outs + N;                  // [4]
     unsigned char *mulb = reinterpret_cast<unsigned char *>(flag + 4); // [q][q]
     // graph tables as u16 in LDS: a global load whose value steers a branch or an address costs ~1 us each,
@@ -324,7 +325,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
     }
 
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
-    for (int i = tid; i < q * TCP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+    for (int i = tid; i < TC * QP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
     if (tid == 0) flag[0] = 0;
     __syncthreads();
 
@@ -354,7 +355,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
 #pragma unroll
             for (int d = 0; d < DVM; d++) {
                 const int dd = min(d, dv - 1);
-                evoff[ci][d] = mulb[sym * q + t_vn_gf[col * dv + dd]] * TCP + t_vn_thr[col * dv + dd];
+                evoff[ci][d] = t_vn_thr[col * dv + dd] * QP + mulb[sym * q + t_vn_gf[col * dv + dd]];
                 if (d < w) wmask |= 1u << (ci * DVM + d);
             }
         }
@@ -374,8 +375,8 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
             } else {
                 const int dd = min(d, dv - 1);
                 const int thr = t_vn_thr[col * dv + dd], h = t_vn_gf[col * dv + dd];
-                e0 = E[thr];
-                ev = E[mulb[sym * q + h] * TCP + thr];
+                e0 = E[thr * QP];
+                ev = E[thr * QP + mulb[sym * q + h]];
                 on = d < w;
             }
             const float c = nb_div12(ev - e0); // :309, double division
@@ -458,7 +459,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
                     const int symk = (idx < q - 1) ? idx + 1 : 0;
                     float2 pr;
                     pr.x = pairs[edge * PST + 2 * idx];
-                    pr.y = __int_as_float((int)mulb[symk * q + t_vn_gf[edge]]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
+                    pr.y = __int_as_float((int)mulb[symk * q + t_vn_gf[edge]] << 2); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334, as a byte offset
                     *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * lane) = pr;
                 }
             }
@@ -471,11 +472,11 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
             const int row = tid / dc, e = tid - row * dc, w = t_cn_w[row];
             if (e < w && !(NB_ABLATE & 1)) {
                 switch (w) {
-                case 2: nb_cn_update<2, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
-                case 3: nb_cn_update<3, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
-                case 4: nb_cn_update<4, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
-                case 5: nb_cn_update<5, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
-                case 6: nb_cn_update<6, Q>(a, t_cn_src, pairs, E, TCP, row, e, tid); break;
+                case 2: nb_cn_update<2, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                case 3: nb_cn_update<3, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                case 4: nb_cn_update<4, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                case 5: nb_cn_update<5, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                case 6: nb_cn_update<6, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
                 default: break;
                 }
             }
@@ -503,8 +504,8 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         float *o = a.c2v + ((size_t)frame * TC + tid) * (q - 1);
         if (e < t_cn_w[row]) {
             const int h = t_cn_gf[tid];
-            const float e0 = E[tid];
-            for (int k = 1; k < q; k++) o[k - 1] = nb_div12(E[mulb[k * q + h] * TCP + tid] - e0);
+            const float e0 = E[tid * QP];
+            for (int k = 1; k < q; k++) o[k - 1] = nb_div12(E[tid * QP + mulb[k * q + h]] - e0);
         } else {
             for (int k = 1; k < q; k++) o[k - 1] = 0.0f;
         }
