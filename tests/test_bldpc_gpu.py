@@ -356,3 +356,25 @@ def test_reference_signature_shim_cpp_harness(C, tmp_path):
     assert "hash=99f71dc5 iteraTime=6 flags=32/32" in out, out
     out = subprocess.check_output([exe, m, "4", "24", "96", "32", "4.0", "1"]).decode()
     assert "hash=90c5df9b iteraTime=50" in out, out
+
+
+def test_bench_contract_line(C):
+    """bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--frames", "2048", "--steps", "2", "--warmup", "1",
+                                   "--cpu-frames", "32"], stderr=subprocess.DEVNULL).decode().strip().splitlines()
+    lines = [ln for ln in out if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["unit"] == "codewords/s" and j["value"] > 0 and "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
