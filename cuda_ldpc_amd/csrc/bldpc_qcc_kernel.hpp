@@ -1,6 +1,7 @@
 // bldpc_qcc_kernel.hpp -- fused QC min-sum kernel with COMPRESSED check-node state (BLDPC_KERNEL_QC_LDS,
 // second tier): for codes whose per-edge messages (4E bytes per frame) do not fit LDS but whose check
-// states do -- the reference's default PON matrix (J12_L69_Z256), its Z = 160 family and J4_L24_Z512.
+// states do -- the reference's Z = 160 family (and any other Z = 256 / 512 shape the register-state kernel of
+// bldpc_qcr_kernel.hpp has no instantiation for).
 //
 // A check row's outputs take only two magnitudes: R_p = +-min1, except +-min2 on the (first) edge that holds
 // the minimum (bldpc_实习/LDPC_Decoder.cu:298-312).  So instead of one message per edge the CN phase publishes
@@ -8,7 +9,8 @@
 // output.  The VN phase rebuilds R for each of its edges from the check's state (same bits as the stored
 // message would have had), sums in the reference's order and publishes the a-posteriori value S; the CN
 // phase rebuilds its own previous outputs the same way, forms Q = S - R (LDPC_Decoder.cu:206-209) and
-// runs min-sum.  LDS per frame: 12 M + 4 (N + Z) bytes instead of 4 E + 4 N.
+// runs min-sum.  LDS per frame: 12 (M + Z) + 4 (N + Z) bytes instead of 4 E + 4 N (Z extra states stay zero: the padding
+// entries of a column's edge list point at them and add R = +0; one extra column stays +inf for the padding slots of a row).
 //
 // One frame per workgroup; lanes run along the circulant dimension; a thread group of U = Z rounded up to
 // whole waves makes the group index wave-uniform, so the per-edge tables (block column / row, position,
