@@ -862,6 +862,16 @@ inline const QcVariant *qc_variants(int *count)
         XC(256, 256, 4, 18, 24) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22)       */
         XC(160, 192, 5, 12, 24) /* the Z = 160 family, J10 ... J48, L60                                   */
         XC(512, 512, 2, 12, 24) /* J4_L24_Z512                                                            */
+        /* lifting sizes outside the reference's matrix set (its users swap matrices by editing define.cuh): the same
+         * generic kernel, any J <= 62 and L <= CPT*G whose states fit LDS; everything else runs on the table kernels */
+        XC(64, 64, 16, 8, 24)   /* Z =  64: L <= 128 */
+        XC(96, 128, 8, 12, 24)  /* Z =  96: L <=  96 */
+        XC(128, 128, 8, 12, 24) /* Z = 128: L <=  96 */
+        XC(192, 192, 5, 16, 24) /* Z = 192: L <=  80 */
+        XC(320, 320, 3, 24, 24) /* Z = 320: L <=  72 */
+        XC(384, 384, 2, 32, 24) /* Z = 384: L <=  64 */
+        XC(640, 640, 1, 40, 24) /* Z = 640: L <=  40 */
+        XC(1024, 1024, 1, 32, 24) /* Z = 1024: L <= 32 */
         /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp): long blocks with 4 N <= LDS */
         XR(15, 30, 1280, 768, 8, 7, 10) /* J15_L30_Z1280 (BASELINE config 4): 12 waves, 8 of them cover 2 tiles of Z (5 tiles per SIMD) */
     };

@@ -378,3 +378,39 @@ def test_bench_contract_line(C):
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+@pytest.mark.parametrize("Z,J,L", [(64, 5, 12), (96, 3, 9), (128, 6, 20), (192, 4, 16), (320, 5, 11), (384, 3, 24), (640, 4, 10), (1024, 3, 8)])
+def test_other_lifting_sizes_random_matrices(C, orc, tmp_path, Z, J, L):
+    """Random block matrices with lifting sizes the reference's matrix set does not contain: the generic compressed-state
+    kernel is picked (these shapes have no ahead-of-time messages-in-LDS variant) and agrees with the oracle and the table kernels."""
+    rng = np.random.default_rng(Z + J)
+    H = rng.integers(0, Z, size=(J, L)).astype(np.int32)
+    H[rng.random((J, L)) < 0.45] = -1
+    for l in range(L):  # every column keeps at least two blocks, every row at least three
+        rows = rng.permutation(J)[:2]
+        for r in rows:
+            if H[r, l] < 0:
+                H[r, l] = rng.integers(0, Z)
+    for j in range(J):
+        cols = rng.permutation(L)[:3]
+        for c in cols:
+            if H[j, c] < 0:
+                H[j, c] = rng.integers(0, Z)
+    path = str(tmp_path / "H.txt")
+    with open(path, "w") as f:
+        for j in range(J):
+            f.write("\t".join(str(int(x)) for x in H[j]) + "\r\n")
+    F = 5
+    y = _channel(orc, L * Z, F, 1.0)
+    ocode = orc.BinaryCode(path, J, L, Z)
+    code = C.BinaryCode.from_blockh(path, J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 8, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=8, exit_mode=C.EXIT_FIXED, want_app=True)
+    assert "compressed" in code.last_kernel, code.last_kernel
+    _assert_same(got, want, code.N, F)
+    got = _decode(C, code, y, F, max_iter=8, exit_mode=C.EXIT_FIXED, kernel=C.KERNEL_TABLE, want_app=True)
+    _assert_same(got, want, code.N, F)
+    want = orc.bldpc_decode(ocode, y, F, 30, early_exit=1, want_app=True)
+    got = _decode(C, code, y, F, max_iter=30, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
+    _assert_same(got, want, code.N, F)
