@@ -651,7 +651,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     // per-edge tables, wave-uniform; read through the constant address space: scalar loads whatever else the kernel stores
     typedef __attribute__((address_space(4))) const unsigned qcc_cu32;
     const qcc_cu32 *cmeta = (const qcc_cu32 *)a.cn_meta; // [J][WCS] row slots, then [J] row weights
-    const qcc_cu32 *vmeta = (const qcc_cu32 *)a.vn_meta; // [L][WVS] column edges, padded to a multiple of 4 with zero-state entries
+    const qcc_cu32 *vmeta = (const qcc_cu32 *)a.vn_meta; // [L][WVS] column edges, padded to a multiple of 2 with zero-state entries
 
     // ---- prologue -----------------------------------------------------------------------------------------
     for (int j = g; j < J + 1; j += G)
@@ -677,6 +677,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     unsigned long long hist = 0;
     __syncthreads();
 
+    constexpr int VR = 2; // column edges per straight-line round (lists are padded to a multiple of it with zero-state entries)
     auto vn_phase = [&](bool &bad) {
 #pragma unroll
         for (int cc = 0; cc < CPT; cc++) {
@@ -684,22 +685,22 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
             if (l < L) { // wave-uniform
                 float S = 0.0f;
                 const qcc_cu32 *vm = vmeta + l * a.WVS;
-                for (int k0 = 0; k0 < wcol[cc]; k0 += 4) { // four edges per round, straight-line (the list is padded)
-                    float mm[4][2], w2f[4][1];
-                    int pos[4];
+                for (int k0 = 0; k0 < wcol[cc]; k0 += VR) { // VR edges per round, straight-line (the list is padded)
+                    float mm[VR][2], w2f[VR][1];
+                    int pos[VR];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < VR; i++) {
                         const unsigned m = vm[k0 + i]; // scalar load
                         const int j = m & 63, sh = m >> 11;
                         pos[i] = (m >> 6) & 31;
-                        int r = t - sh;
-                        r = (r < 0) ? r + Z : r;
+                        const unsigned r1 = (unsigned)(t - sh);
+                        const int r = (int)min(r1, r1 + (unsigned)Z); // t - sh wraps to a huge value when negative
                         const int sidx = j * Z + r;
                         lds_ld<2>(mm[i], lds, sidx * 8);
                         lds_ld<1>(w2f[i], lds, off_w2 + sidx * 4);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; i++) S += qcc_recon(mm[i][0], mm[i][1], f2u(w2f[i][0]), pos[i]); // ascending block row = the reference's edge order
+                    for (int i = 0; i < VR; i++) S += qcc_recon(mm[i][0], mm[i][1], f2u(w2f[i][0]), pos[i]); // ascending block row = the reference's edge order
                 }
                 S += yreg[cc];
                 if (lane_on) {
@@ -748,8 +749,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
                     for (int i = 0; i < CHK; i++) {
                         const unsigned m = cm[p0 + i]; // scalar load; padding slots point at the +inf column with shift 0
                         const int col = m & 255, sh = m >> 8;
-                        int c = t + sh;
-                        c = (c >= Z) ? c - Z : c;
+                        const unsigned c1 = (unsigned)(t + sh);
+                        const int c = (int)min(c1, c1 - (unsigned)Z); // c1 - Z wraps to a huge value unless c1 >= Z
                         float sv[1];
                         lds_ld<1>(sv, lds, off_S + (col * Z + c) * 4);
                         Sv[i] = sv[0];
@@ -985,7 +986,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
     }
     if (v.U) { // meta tables of the compressed-state kernel
-        const int WVS = (Wv + 3) / 4 * 4; // column edge lists padded to whole rounds of 4 with entries of the zero state (row J)
+        const int WVS = (Wv + 1) / 2 * 2; // column edge lists padded to whole rounds of 2 with entries of the zero state (row J)
         q->WVS = WVS;
         std::vector<unsigned> cm((size_t)J * v.WC + J, qcc_cn_meta(L, 0)), vm((size_t)L * WVS, qcc_vn_meta(J, 0, 0));
         std::vector<int> fillc(L, 0);
