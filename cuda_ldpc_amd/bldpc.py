@@ -13,7 +13,7 @@ import torch
 
 from ._lib import check, lib
 
-EXIT_FIXED, EXIT_BATCH_GLOBAL = 0, 1
+EXIT_FIXED, EXIT_BATCH_GLOBAL, EXIT_PER_FRAME = 0, 1, 2
 KERNEL_AUTO, KERNEL_TABLE, KERNEL_QC_LDS = 0, 1, 2
 
 
@@ -141,6 +141,9 @@ def LDPC_Decoder_GPU(code, Channel_Out, max_iter=50, length=0, exit_mode=EXIT_BA
 
     Channel_Out: CUDA float32 tensor [N, F] (frame-fastest, as the reference).
     Returns dict(D=int32 [N+1, F] on device, iteraTime=int, app=[N, F] or None, flag_hist=uint64-as-int64 [F] or None).
+
+    exit_mode=EXIT_PER_FRAME (bldpc_decode_per_frame): every frame stops on its own flag, as the reference does with a
+    batch of one frame; the result then carries iters=int32 [F] on the device (iterations per frame) and iteraTime is None.
     """
     if not (Channel_Out.is_cuda and Channel_Out.dtype == torch.float32 and Channel_Out.is_contiguous()):
         raise ValueError("Channel_Out must be a contiguous CUDA float32 tensor")
@@ -154,6 +157,13 @@ def LDPC_Decoder_GPU(code, Channel_Out, max_iter=50, length=0, exit_mode=EXIT_BA
     hist = torch.zeros(F, dtype=torch.int64, device=dev) if want_flag_hist else None
     it = ctypes.c_int(0)
     st = ctypes.c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
+    if exit_mode == EXIT_PER_FRAME:
+        if want_flag_hist:
+            raise ValueError("flag history is not returned with per-frame exit (iters holds each frame's stop iteration)")
+        iters = torch.empty(F, dtype=torch.int32, device=dev)
+        check(lib.bldpc_decode_per_frame(code._h, _dev_ptr(Channel_Out), F, max_iter, length, kernel, _dev_ptr(D), _dev_ptr(app),
+                                         _dev_ptr(iters), st), "LDPC_Decoder_GPU")
+        return dict(D=D, iteraTime=None, app=app, flag_hist=None, iters=iters)
     check(lib.bldpc_decode(code._h, _dev_ptr(Channel_Out), F, max_iter, length, exit_mode, kernel, _dev_ptr(D), _dev_ptr(app),
                            _dev_ptr(hist), ctypes.byref(it), st), "LDPC_Decoder_GPU")
     return dict(D=D, iteraTime=it.value, app=app, flag_hist=hist)
@@ -180,12 +190,17 @@ class SimCounters:
 def Statistic(SIM, code, D, iteraTime, length=0, CodeWord=None, leastErrorFrames=50, leastTestFrames=10000, stream=None):
     """Statistic (Simulation.cu:245-285) on the device; returns the reference's stop flag.
 
-    The caller adds the batch to SIM.num_Frames first, like Simulation_GPU does (Simulation.cu:113)."""
+    The caller adds the batch to SIM.num_Frames first, like Simulation_GPU does (Simulation.cu:113).
+    iteraTime: the batch's iteration count (int), or the per-frame counts of EXIT_PER_FRAME (CUDA int32 tensor [F])."""
     F = int(D.shape[1])
     if SIM._dev is None:
         SIM._dev = torch.zeros(5, dtype=torch.int64, device=D.device)
     st = ctypes.c_void_p((stream or torch.cuda.current_stream(D.device)).cuda_stream)
-    check(lib.bldpc_statistic(code._h, _dev_ptr(D), _dev_ptr(CodeWord), F, length, iteraTime, _dev_ptr(SIM._dev), st), "Statistic")
+    if torch.is_tensor(iteraTime):
+        check(lib.bldpc_statistic_per_frame(code._h, _dev_ptr(D), _dev_ptr(CodeWord), F, length, _dev_ptr(iteraTime), _dev_ptr(SIM._dev), st),
+              "Statistic")
+    else:
+        check(lib.bldpc_statistic(code._h, _dev_ptr(D), _dev_ptr(CodeWord), F, length, iteraTime, _dev_ptr(SIM._dev), st), "Statistic")
     c = SIM._dev.cpu().tolist()
     SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, SIM.num_False_Frames, SIM.num_Alarm_Frames = c
     return 1 if (SIM.num_Error_Frames >= leastErrorFrames and SIM.num_Frames >= leastTestFrames) else 0

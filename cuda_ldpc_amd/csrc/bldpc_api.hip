@@ -247,16 +247,19 @@ extern "C" int bldpc_last_kernel_ms(bldpc_code *c, float *ms)
 // ---------------------------------------------------------------------------
 template <int VEC>
 static int run_table(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
-                     unsigned long long *flag_hist, int *itera, hipStream_t st)
+                     unsigned long long *flag_hist, int *itera, int *iters, hipStream_t st)
 {
+    const bool early = exit_mode != BLDPC_EXIT_FIXED; // the host watches the flags: stop when every frame is flagged / has stopped
     TableArgs a;
     a.rq = (float *)c->rq.p; a.y = y; a.addr = c->d_addr; a.node_list = c->d_node_list;
     a.wv_blk = c->d_wv_blk; a.wc_blk = c->d_wc_blk;
     a.F = F; a.Z = c->Z; a.Wv = c->Wv; a.Wc = c->Wc; a.length = length;
+    a.iters = (exit_mode == BLDPC_EXIT_PER_FRAME) ? iters : nullptr;
+    if (a.iters) CLDPC_HIP(hipMemsetAsync(iters, 0, (size_t)F * sizeof(int), st), BLDPC_EHIP);
     int *bad = (int *)c->bad.p, *cnt = (int *)c->cnt.p;
     const dim3 blk(256);
     const unsigned gx = (unsigned)((F + VEC * 256 - 1) / (VEC * 256));
-    const bool per_iter_flags = (exit_mode == BLDPC_EXIT_BATCH_GLOBAL) || flag_hist;
+    const bool per_iter_flags = early || flag_hist;
     CLDPC_HIP(hipMemsetAsync(c->rq.p, 0, (size_t)c->M * c->Wc * F * sizeof(float), st), BLDPC_EHIP); // LDPC_Decoder.cu:82
     CLDPC_HIP(hipMemsetAsync(bad, 0, (size_t)F * sizeof(int), st), BLDPC_EHIP);
     if (flag_hist) CLDPC_HIP(hipMemsetAsync(flag_hist, 0, (size_t)F * sizeof(unsigned long long), st), BLDPC_EHIP);
@@ -264,7 +267,7 @@ static int run_table(bldpc_code *c, const float *y, int F, int max_iter, int len
     while (it < max_iter) {
         it++;
         const bool last = (it == max_iter);
-        const bool want_out = last || exit_mode == BLDPC_EXIT_BATCH_GLOBAL; // D must be current whenever we may stop
+        const bool want_out = last || early; // D must be current whenever we may stop
         a.D = want_out ? D : nullptr;
         a.app = (want_out && app) ? app : nullptr;
         a.bad = (per_iter_flags || last) ? bad : nullptr;
@@ -273,13 +276,13 @@ static int run_table(bldpc_code *c, const float *y, int F, int max_iter, int len
             if (cntn <= 0) continue;
             hipLaunchKernelGGL(k_table_vn<VEC>, dim3(gx, (unsigned)std::min(cntn, 65535)), blk, 0, st, a, n0, cntn);
         }
-        if (!last || exit_mode == BLDPC_EXIT_BATCH_GLOBAL) // the CN pass after the final VN pass is unobservable
+        if (!last || exit_mode == BLDPC_EXIT_BATCH_GLOBAL) // the CN pass after the final VN pass is unobservable (the reference runs it)
             hipLaunchKernelGGL(k_table_cn<VEC>, dim3(gx, (unsigned)std::min(c->M, 65535)), blk, 0, st, a, c->M);
         if (per_iter_flags || last) {
-            const bool need_cnt = exit_mode == BLDPC_EXIT_BATCH_GLOBAL;
+            const bool need_cnt = early;
             if (need_cnt) CLDPC_HIP(hipMemsetAsync(cnt, 0, sizeof(int), st), BLDPC_EHIP);
             hipLaunchKernelGGL(k_flags, dim3((F + 255) / 256), blk, 0, st, bad, want_out ? D + (size_t)c->N * F : nullptr,
-                               flag_hist, need_cnt ? cnt : nullptr, F, it);
+                               flag_hist, need_cnt ? cnt : nullptr, F, it, const_cast<int *>(a.iters), last ? 1 : 0);
             if (need_cnt) {
                 CLDPC_HIP(hipMemcpyAsync(c->h_cnt, cnt, sizeof(int), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
                 CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
@@ -292,14 +295,15 @@ static int run_table(bldpc_code *c, const float *y, int F, int max_iter, int len
     return BLDPC_OK;
 }
 
-extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int kernel, int *D,
-                            float *app, unsigned long long *flag_hist, int *itera, void *stream)
+static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int kernel, int *D, float *app,
+                       unsigned long long *flag_hist, int *itera, int *iters, void *stream)
 {
     if (!c || !y || !D || !itera) return fail(BLDPC_EINVAL, "bldpc_decode: null argument");
     if (F <= 0 || max_iter <= 0) return fail(BLDPC_EINVAL, "bldpc_decode: F=%d max_iter=%d must be positive", F, max_iter);
     if (length == 0) length = c->K;
     if (length < 0 || length > c->N) return fail(BLDPC_EINVAL, "bldpc_decode: length=%d outside [0,%d]", length, c->N);
-    if (exit_mode != BLDPC_EXIT_FIXED && exit_mode != BLDPC_EXIT_BATCH_GLOBAL) return fail(BLDPC_EINVAL, "unknown exit_mode %d", exit_mode);
+    if (exit_mode != BLDPC_EXIT_FIXED && exit_mode != BLDPC_EXIT_BATCH_GLOBAL && exit_mode != BLDPC_EXIT_PER_FRAME)
+        return fail(BLDPC_EINVAL, "unknown exit_mode %d", exit_mode);
     hipStream_t st = (hipStream_t)stream;
     const bool qc_ok = c->has_qc && c->qc.frames_per_wg > 0;
     if (kernel == BLDPC_KERNEL_AUTO) kernel = qc_ok ? BLDPC_KERNEL_QC_LDS : BLDPC_KERNEL_TABLE;
@@ -312,7 +316,7 @@ extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, 
         CLDPC_HIP(c->bits.reserve((size_t)F * (c->N / 32) * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(c->yg.reserve(((size_t)F + 2) * c->N * sizeof(float)), BLDPC_ENOMEM);
         int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
-                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, st,
+                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, iters, st,
                           c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr);
         c->last_kernel = c->qc.name;
         return r;
@@ -326,17 +330,33 @@ extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, 
     int r;
     if (F % 4 == 0 && a16) {
         c->last_kernel = "table_vec4";
-        r = run_table<4>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+        r = run_table<4>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, iters, st);
     } else {
         c->last_kernel = "table_vec1";
-        r = run_table<1>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, st);
+        r = run_table<1>(c, y, F, max_iter, length, exit_mode, D, app, flag_hist, itera, iters, st);
     }
     if (c->profiling) CLDPC_HIP(hipEventRecord(c->ev1, st), BLDPC_EHIP);
     return r;
 }
 
-extern "C" int bldpc_statistic(const bldpc_code *cc, const int *D, const int *cw, int F, int length, int itera, long long *counters,
-                               void *stream)
+extern "C" int bldpc_decode(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int kernel, int *D,
+                            float *app, unsigned long long *flag_hist, int *itera, void *stream)
+{
+    if (exit_mode == BLDPC_EXIT_PER_FRAME)
+        return fail(BLDPC_EINVAL, "bldpc_decode: per-frame exit returns one iteration count per frame, use bldpc_decode_per_frame");
+    return decode_impl(c, y, F, max_iter, length, exit_mode, kernel, D, app, flag_hist, itera, nullptr, stream);
+}
+
+extern "C" int bldpc_decode_per_frame(bldpc_code *c, const float *y, int F, int max_iter, int length, int kernel, int *D, float *app,
+                                      int *iters, void *stream)
+{
+    if (!iters) return fail(BLDPC_EINVAL, "bldpc_decode_per_frame: null iters");
+    int unused = 0;
+    return decode_impl(c, y, F, max_iter, length, BLDPC_EXIT_PER_FRAME, kernel, D, app, nullptr, &unused, iters, stream);
+}
+
+static int statistic_impl(const bldpc_code *cc, const int *D, const int *cw, int F, int length, int itera, const int *iters,
+                          long long *counters, void *stream)
 {
     bldpc_code *c = const_cast<bldpc_code *>(cc); // scratch only
     if (!c || !D || !counters || F <= 0) return fail(BLDPC_EINVAL, "bldpc_statistic: bad argument");
@@ -353,7 +373,20 @@ extern "C" int bldpc_statistic(const bldpc_code *cc, const int *D, const int *cw
         hipLaunchKernelGGL(k_stat_errors, dim3((unsigned)((F + 1023) / 1024), (unsigned)slices), dim3(256), 0, st, D, cw, F, length, rows,
                            (int *)c->errs.p);
     hipLaunchKernelGGL(k_stat_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, (int *)c->errs.p, D + (size_t)c->N * F, F, itera,
-                       counters);
+                       iters, counters);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
+}
+
+extern "C" int bldpc_statistic(const bldpc_code *cc, const int *D, const int *cw, int F, int length, int itera, long long *counters,
+                               void *stream)
+{
+    return statistic_impl(cc, D, cw, F, length, itera, nullptr, counters, stream);
+}
+
+extern "C" int bldpc_statistic_per_frame(const bldpc_code *cc, const int *D, const int *cw, int F, int length, const int *iters,
+                                         long long *counters, void *stream)
+{
+    if (!iters) return fail(BLDPC_EINVAL, "bldpc_statistic_per_frame: null iters");
+    return statistic_impl(cc, D, cw, F, length, 0, iters, counters, stream);
 }

@@ -68,6 +68,11 @@ struct QcArgs {
     const unsigned *vn_meta;    // [L][WVS] column edges, top -> bottom
     int J, L, WVS;
     int lc;                     // register-state kernel (k_qcr): the block column kept in registers
+    // per-frame exit (HIST instantiations only): a frame stops at the first iteration at which ITS flag is set --
+    // the reference rule (LDPC_Decoder.cu:134-153) with Num_Frames_OneTime = 1 -- its outputs are those of that
+    // iteration, and the workgroup leaves when all of its frames have stopped
+    int per_frame;
+    int *iters;                 // [F] iterations executed per frame (per_frame only)
 };
 
 template <int NF> struct Msg;
@@ -103,7 +108,7 @@ template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int G_, int MINW_> 
     static constexpr int zero_slot = Sslot + L * Z; // always +0.0f
     static constexpr int inf_slot = zero_slot + 1;  // always +inf
     static constexpr int flag_byte = (inf_slot + 1) * MSG;
-    static constexpr int lds_bytes = flag_byte + NF * 4;
+    static constexpr int lds_bytes = flag_byte + NF * 8; // flag words: [2][NF], see flags_publish
     static constexpr int NW = (L * Z) / 32;         // 32-bit words of hard bits per frame
     static_assert(TPB % 64 == 0 && TPB <= 1024, "workgroup must be whole waves");
     static_assert(Z % 32 == 0, "half-waves must not straddle a thread group");
@@ -191,8 +196,11 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         reinterpret_cast<float *>(lds)[GM::zero_slot * NF + tid] = 0.0f;
         reinterpret_cast<float *>(lds)[GM::inf_slot * NF + tid] = __builtin_inff();
         lds_flag[tid] = 0;
+        lds_flag[NF + tid] = 0;
     }
     unsigned long long hist = 0; // used by threads tid < NF
+    unsigned done = 0;           // per-frame exit: frames of this workgroup that have stopped (workgroup-uniform)
+    constexpr unsigned ALL = (1u << NF) - 1u;
     __syncthreads();
 
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
@@ -229,20 +237,57 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         }
     };
 
-    // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147)
-    auto flags_publish = [&](const bool (&bad)[NF]) {
+    // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147).  Two sets of flag words, used by odd and even
+    // iterations in turn: the set read after this iteration's barrier is not written again before the next one, so
+    // every thread may read it (per-frame exit) while threads tid < NF clear the other set for the next iteration.
+    auto flags_publish = [&](const bool (&bad)[NF], int it) {
 #pragma unroll
         for (int v = 0; v < NF; v++)
-            if (bad[v]) lds_flag[v] = 1; // same value from every writer
+            if (bad[v]) lds_flag[(it & 1) * NF + v] = 1; // same value from every writer
     };
     auto flags_collect = [&](int it) -> int {
         int flag = 0;
         if (tid < NF) {
-            flag = lds_flag[tid] ? 0 : 1;
-            lds_flag[tid] = 0;
+            flag = lds_flag[(it & 1) * NF + tid] ? 0 : 1;
+            lds_flag[((it + 1) & 1) * NF + tid] = 0;
             if (flag && it <= 64) hist |= (1ull << (it - 1));
         }
         return flag;
+    };
+    // hard bits (and a-posteriori values) of the frames in `mask`, from the S values this thread has just published
+    auto emit = [&](unsigned mask, bool (&bad)[NF]) {
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            const int n = (g + cc * G) * Z + t;
+            float S[NF];
+            lds_ld<NF>(S, lds, sbase + cc * G * Z * MSG); // own value, just written
+#pragma unroll
+            for (int v = 0; v < NF; v++) {
+                if (HIST && !((mask >> v) & 1u)) continue; // workgroup-uniform
+                const bool neg = S[v] < 0;
+                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
+                // hard bits leave packed, one 32-bit word per half-wave: Z % 32 == 0 keeps the 32 lanes of a
+                // half-wave inside one thread group, i.e. on 32 consecutive variables n .. n+31, n % 32 == 0.
+                const unsigned long long m = __ballot(neg);
+                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
+            }
+        }
+    };
+    // per-frame exit: frames whose flag has just come up leave with this iteration's outputs
+    auto retire = [&](int it) -> bool {
+        unsigned newly = 0;
+#pragma unroll
+        for (int v = 0; v < NF; v++)
+            if (!lds_flag[(it & 1) * NF + v]) newly |= 1u << v;
+        newly &= ~done;
+        if (newly) {
+            bool unused[NF];
+            emit(newly, unused);
+            if (tid < NF && ((newly >> tid) & 1u) && f0 + tid < F) a.iters[f0 + tid] = it;
+            done |= newly;
+        }
+        return done == ALL;
     };
 
     // ---- iterations 1 .. max_iter-1: VN, CN --------------------------------------------------
@@ -257,9 +302,12 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
         vn_phase(bad);
-        if (HIST) flags_publish(bad);
+        if (HIST) flags_publish(bad, it);
         if (!(QC_ABLATE & 4)) __syncthreads();
-        if (HIST) (void)flags_collect(it);
+        if (HIST) {
+            (void)flags_collect(it);
+            if (a.per_frame && retire(it)) break;
+        }
 
         // CN phase (LDPC_Decoder.cu:279-314)
 #pragma unroll
@@ -317,34 +365,22 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     }
 
     // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -----------
-    {
+    int flag = 0;
+    if (!(HIST && done == ALL)) {
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
         vn_phase(bad);
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int n = (g + cc * G) * Z + t;
-            float S[NF];
-            lds_ld<NF>(S, lds, sbase + cc * G * Z * MSG); // own value, just written
-#pragma unroll
-            for (int v = 0; v < NF; v++) {
-                const bool neg = S[v] < 0;
-                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
-                // hard bits leave packed, one 32-bit word per half-wave: Z % 32 == 0 keeps the 32 lanes of a
-                // half-wave inside one thread group, i.e. on 32 consecutive variables n .. n+31, n % 32 == 0.
-                const unsigned long long m = __ballot(neg);
-                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
-                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
-            }
-        }
-        flags_publish(bad);
+        emit(~done, bad);
+        flags_publish(bad, a.max_iter);
         __syncthreads();
-        const int flag = flags_collect(a.max_iter);
-        if (tid < NF && f0 + tid < F) {
-            a.D[(size_t)L * Z * F + f0 + tid] = flag;
-            if (HIST && a.hist) a.hist[f0 + tid] = hist;
-        }
+        flag = flags_collect(a.max_iter);
+    }
+    if (tid < NF && f0 + tid < F) {
+        const bool stopped = HIST && ((done >> tid) & 1u);
+        a.D[(size_t)L * Z * F + f0 + tid] = stopped ? 1 : flag;
+        if (HIST && a.hist) a.hist[f0 + tid] = hist;
+        if (HIST && a.per_frame && !stopped) a.iters[f0 + tid] = a.max_iter;
     }
 }
 
@@ -364,7 +400,7 @@ template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int GJ_, int MINW_>
     static constexpr int zero_slot = Sslot + L * Z;
     static constexpr int inf_slot = zero_slot + 1;
     static constexpr int flag_byte = (inf_slot + 1) * MSG;
-    static constexpr int lds_bytes = flag_byte + NF * 4;
+    static constexpr int lds_bytes = flag_byte + NF * 8;
     static constexpr int NW = (L * Z) / 32;
     static_assert(Z % 32 == 0 && WC % 2 == 0, "half-waves own 32 circulant positions and half a row each");
     static_assert(J % GJ == 0 && L % NCG == 0, "groups must tile the block rows and columns");
@@ -447,8 +483,11 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         reinterpret_cast<float *>(lds)[GM::zero_slot * NF + tid] = 0.0f;
         reinterpret_cast<float *>(lds)[GM::inf_slot * NF + tid] = __builtin_inff();
         lds_flag[tid] = 0;
+        lds_flag[NF + tid] = 0;
     }
     unsigned long long hist = 0;
+    unsigned done = 0; // per-frame exit, see k_qc
+    constexpr unsigned ALL = (1u << NF) - 1u;
     __syncthreads();
 
     auto vn_phase = [&](bool (&bad)[NF]) {
@@ -477,19 +516,50 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             }
         }
     };
-    auto flags_publish = [&](const bool (&bad)[NF]) {
+    auto flags_publish = [&](const bool (&bad)[NF], int it) { // two sets of flag words by iteration parity, see k_qc
 #pragma unroll
         for (int v = 0; v < NF; v++)
-            if (bad[v]) lds_flag[v] = 1;
+            if (bad[v]) lds_flag[(it & 1) * NF + v] = 1;
     };
     auto flags_collect = [&](int it) -> int {
         int flag = 0;
         if (tid < NF) {
-            flag = lds_flag[tid] ? 0 : 1;
-            lds_flag[tid] = 0;
+            flag = lds_flag[(it & 1) * NF + tid] ? 0 : 1;
+            lds_flag[((it + 1) & 1) * NF + tid] = 0;
             if (flag && it <= 64) hist |= (1ull << (it - 1));
         }
         return flag;
+    };
+    auto emit = [&](unsigned mask, bool (&bad)[NF]) {
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            const int n = (cg + cc * NCG) * Z + t;
+            float S[NF];
+            lds_ld<NF>(S, lds, sbase + cc * NCG * Z * MSG);
+#pragma unroll
+            for (int v = 0; v < NF; v++) {
+                if (HIST && !((mask >> v) & 1u)) continue; // workgroup-uniform
+                const bool neg = S[v] < 0;
+                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
+                const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave, see k_qc
+                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
+            }
+        }
+    };
+    auto retire = [&](int it) -> bool { // per-frame exit, see k_qc
+        unsigned newly = 0;
+#pragma unroll
+        for (int v = 0; v < NF; v++)
+            if (!lds_flag[(it & 1) * NF + v]) newly |= 1u << v;
+        newly &= ~done;
+        if (newly) {
+            bool unused[NF];
+            emit(newly, unused);
+            if (tid < NF && ((newly >> tid) & 1u) && f0 + tid < F) a.iters[f0 + tid] = it;
+            done |= newly;
+        }
+        return done == ALL;
     };
 
     for (int it = 1; it < a.max_iter; it++) {
@@ -497,9 +567,12 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
         vn_phase(bad);
-        if (HIST) flags_publish(bad);
+        if (HIST) flags_publish(bad, it);
         __syncthreads();
-        if (HIST) (void)flags_collect(it);
+        if (HIST) {
+            (void)flags_collect(it);
+            if (a.per_frame && retire(it)) break;
+        }
 
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
@@ -547,32 +620,22 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         __syncthreads();
     }
 
-    {
+    int flag = 0;
+    if (!(HIST && done == ALL)) { // final iteration: VN only, then outputs
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
         vn_phase(bad);
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int n = (cg + cc * NCG) * Z + t;
-            float S[NF];
-            lds_ld<NF>(S, lds, sbase + cc * NCG * Z * MSG);
-#pragma unroll
-            for (int v = 0; v < NF; v++) {
-                const bool neg = S[v] < 0;
-                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
-                const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave, see k_qc
-                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
-                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
-            }
-        }
-        flags_publish(bad);
+        emit(~done, bad);
+        flags_publish(bad, a.max_iter);
         __syncthreads();
-        const int flag = flags_collect(a.max_iter);
-        if (tid < NF && f0 + tid < F) {
-            a.D[(size_t)L * Z * F + f0 + tid] = flag;
-            if (HIST && a.hist) a.hist[f0 + tid] = hist;
-        }
+        flag = flags_collect(a.max_iter);
+    }
+    if (tid < NF && f0 + tid < F) {
+        const bool stopped = HIST && ((done >> tid) & 1u);
+        a.D[(size_t)L * Z * F + f0 + tid] = stopped ? 1 : flag;
+        if (HIST && a.hist) a.hist[f0 + tid] = hist;
+        if (HIST && a.per_frame && !stopped) a.iters[f0 + tid] = a.max_iter;
     }
 }
 
@@ -673,8 +736,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
         wcol[cc] = (l < L) ? a.wv[l] : 0;
         yreg[cc] = (l < L && lane_on) ? a.y[(size_t)f * N + l * Z + t] : 0.0f;
     }
-    if (tid == 0) lds_flag[0] = 0;
+    if (tid == 0) lds_flag[0] = lds_flag[1] = 0; // two flag words, used by odd and even iterations in turn (see k_qc)
     unsigned long long hist = 0;
+    int stop = 0; // per-frame exit: the iteration at which the frame's flag came up
     __syncthreads();
 
     constexpr int VR = 2; // column edges per straight-line round (lists are padded to a multiple of it with zero-state entries)
@@ -714,8 +778,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     auto flags_collect = [&](int it) -> int {
         int flag = 0;
         if (tid == 0) {
-            flag = lds_flag[0] ? 0 : 1;
-            lds_flag[0] = 0;
+            flag = lds_flag[it & 1] ? 0 : 1;
+            lds_flag[(it + 1) & 1] = 0;
             if (flag && it <= 64) hist |= (1ull << (it - 1));
         }
         return flag;
@@ -724,9 +788,15 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     for (int it = 1; it < a.max_iter; it++) {
         bool bad = false;
         vn_phase(bad);
-        if (HIST && bad) lds_flag[0] = 1;
+        if (HIST && bad) lds_flag[it & 1] = 1;
         __syncthreads();
-        if (HIST) (void)flags_collect(it);
+        if (HIST) {
+            (void)flags_collect(it);
+            if (a.per_frame && !lds_flag[it & 1]) { // the frame stops with the values of this iteration
+                stop = it;
+                break;
+            }
+        }
 
         // CN phase (LDPC_Decoder.cu:279-314) on the compressed state
         for (int j = g; j < J; j += G) { // wave-uniform
@@ -780,7 +850,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
 
     {
         bool bad = false;
-        vn_phase(bad);
+        if (!stop) vn_phase(bad); // final iteration: VN only
         bad = false;
 #pragma unroll
         for (int cc = 0; cc < CPT; cc++) {
@@ -796,12 +866,14 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
                 if (a.app && lane_on) a.app[(size_t)n * F + f] = sv[0];
             }
         }
-        if (bad) lds_flag[0] = 1;
+        const int last = stop ? stop : a.max_iter;
+        if (!stop && bad) lds_flag[last & 1] = 1; // (a stopped frame's verdict is in already)
         __syncthreads();
-        const int flag = flags_collect(a.max_iter);
+        const int flag = stop ? 1 : flags_collect(last);
         if (tid == 0) {
             a.D[(size_t)N * F + f] = flag;
             if (HIST && a.hist) a.hist[f] = hist;
+            if (HIST && a.per_frame) a.iters[f] = last;
         }
     }
 }
@@ -1045,12 +1117,14 @@ inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStre
 
 // y here is the regrouped buffer produced by qc_regroup.
 inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
-                     unsigned long long *hist, unsigned *bits, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+                     unsigned long long *hist, unsigned *bits, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                     int *iters = nullptr)
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
     QcArgs a;
     a.y = y; a.D = D; a.bits = bits; a.app = app; a.hist = hist;
+    a.per_frame = (iters && hist) ? 1 : 0; a.iters = iters; // per-frame exit lives in the flag-tracking instantiation
     a.cn_edges = q->d_cn; a.rowptr = q->d_rowptr; a.vn_edges = q->d_vn; a.wv = q->d_wv;
     a.F = F;
     a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
@@ -1070,7 +1144,7 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 // yg: device float [ceil(F/NF)*NF][N] workspace for the regrouped channel values.
 inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
                      unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, unsigned *bits,
-                     float *yg, int *itera, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+                     float *yg, int *itera, int *iters, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     {
         int rr = qc_regroup(q, y, yg, F, st);
@@ -1080,6 +1154,10 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     if (exit_mode == BLDPC_EXIT_FIXED) {
         *itera = max_iter;
         return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, bits, st, ev0, ev1);
+    }
+    if (exit_mode == BLDPC_EXIT_PER_FRAME) { // every workgroup leaves when its own frames have stopped; nothing to wait for
+        *itera = max_iter;
+        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters);
     }
     // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are
     // flagged.  Pass 1 runs max_iter iterations on-chip recording each frame's flag history; the AND of

@@ -54,7 +54,7 @@ typedef __attribute__((address_space(4))) const unsigned qcr_const_u32;
 // variable (LC, tid + z*TPB), kept in registers across the whole decode.
 template <typename GM, bool HIST, int NZ>
 __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *lds_flag, const __amdgpu_buffer_rsrc_t yrs,
-                                               float (&S0)[GM::ZR], unsigned long long &hist)
+                                               float (&S0)[GM::ZR], unsigned long long &hist, int &stop)
 {
     constexpr int J = GM::J, Z = GM::Z, TPB = GM::TPB, WCS = GM::WCS, MINW = GM::MINW, N = GM::L * Z, NS = N / TPB, YB = GM::YB;
     const int tid = threadIdx.x;
@@ -79,10 +79,10 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
         const unsigned c = min(c1, c1 - (unsigned)Z); // c1 - Z wraps to a huge value unless c1 >= Z
         return (int)(((m & 255u) * (unsigned)Z + c) * 4u);
     };
-    auto flags_collect = [&](int it) {
+    auto flags_collect = [&](int it) { // two flag words, used by odd and even iterations in turn (see k_qc)
         if (tid == 0) {
-            const int flag = lds_flag[0] ? 0 : 1;
-            lds_flag[0] = 0;
+            const int flag = lds_flag[it & 1] ? 0 : 1;
+            lds_flag[(it + 1) & 1] = 0;
             if (flag && it <= 64) hist |= (1ull << (it - 1));
         }
     };
@@ -230,9 +230,15 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (HIST && (badbits >> 31)) lds_flag[0] = 1;
+        if (HIST && (badbits >> 31)) lds_flag[(it + 1) & 1] = 1;
         __syncthreads();
-        if (HIST && it + 1 < a.max_iter) flags_collect(it + 1);
+        if (HIST && it + 1 < a.max_iter) {
+            flags_collect(it + 1);
+            if (a.per_frame && !lds_flag[(it + 1) & 1]) { // per-frame exit: the frame stops with S of iteration it+1
+                stop = it + 1;
+                break;
+            }
+        }
     }
 }
 
@@ -263,22 +269,25 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     float S0[ZR];
 #pragma unroll
     for (int z = 0; z < ZR; z++) S0[z] = (z < ZR - 1 || zlast) ? 0.0f + yf[a.lc * Z + tid + z * TPB] : 0.0f;
-    if (tid == 0) lds_flag[0] = 0;
+    if (tid == 0) lds_flag[0] = lds_flag[1] = 0;
     unsigned long long hist = 0;
+    int stop = 0; // per-frame exit: the iteration at which the frame's flag came up (workgroup-uniform)
     __syncthreads();
     if (HIST) {
-        if (bad) lds_flag[0] = 1;
+        if (bad) lds_flag[1] = 1; // iteration 1
         __syncthreads();
-        if (a.max_iter > 1 && tid == 0) {
-            if (!lds_flag[0]) hist |= 1ull;
-            lds_flag[0] = 0;
+        if (a.max_iter > 1) {
+            if (tid == 0 && !lds_flag[1]) hist |= 1ull;
+            if (a.per_frame && !lds_flag[1]) stop = 1;
         }
     }
 
-    if (GM::RAGGED && !zlast) qcr_iterations<GM, HIST, (GM::RAGGED ? ZR - 1 : ZR)>(a, lds, lds_flag, yrs, S0, hist);
-    else qcr_iterations<GM, HIST, ZR>(a, lds, lds_flag, yrs, S0, hist);
+    if (stop) {
+    } else if (GM::RAGGED && !zlast) qcr_iterations<GM, HIST, (GM::RAGGED ? ZR - 1 : ZR)>(a, lds, lds_flag, yrs, S0, hist, stop);
+    else qcr_iterations<GM, HIST, ZR>(a, lds, lds_flag, yrs, S0, hist, stop);
+    const int last = stop ? stop : a.max_iter;
 
-    // ---- outputs from S of iteration max_iter ----
+    // ---- outputs from S of the last iteration ----
 #pragma unroll
     for (int z = 0; z < ZR; z++)
         if (z < ZR - 1 || zlast) { // column LC comes back from the registers
@@ -296,13 +305,14 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
         if ((tid & 31) == 0) a.bits[(size_t)f * (N / 32) + (n >> 5)] = (unsigned)(m >> (tid & 32));
         if (a.app) a.app[(size_t)n * F + f] = sv[0];
     }
-    if (bad) lds_flag[0] = 1; // (HIST: the last round has already published the same verdict)
+    if (bad) lds_flag[last & 1] = 1; // (HIST: the last round has already published the same verdict)
     __syncthreads();
     if (tid == 0) {
-        const int flag = lds_flag[0] ? 0 : 1;
-        if (flag && a.max_iter <= 64) hist |= (1ull << (a.max_iter - 1));
+        const int flag = lds_flag[last & 1] ? 0 : 1;
+        if (flag && last <= 64) hist |= (1ull << (last - 1));
         a.D[(size_t)N * F + f] = flag;
         if (HIST && a.hist) a.hist[f] = hist;
+        if (HIST && a.per_frame) a.iters[f] = last;
     }
 }
 

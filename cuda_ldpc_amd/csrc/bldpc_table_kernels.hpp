@@ -52,6 +52,8 @@ struct TableArgs {
     int *D;                 // [N+1][F] or nullptr (skip hard-bit store this pass)
     float *app;             // [N][F] or nullptr
     int *bad;               // [F] set to 1 when a frame has a 1 among its first `length` bits (nullptr = skip)
+    const int *iters;       // per-frame exit: [F] iteration at which the frame stopped, 0 = still running (nullptr = off);
+                            // a stopped frame keeps the D / app columns of that iteration
     int F, Z, Wv, Wc, length;
 };
 
@@ -90,13 +92,31 @@ template <int VEC> __global__ __launch_bounds__(256) void k_table_vn(TableArgs a
                 for (int v = 0; v < VEC; v++) Q[v] = S[v] - R[i][v];
                 vstore<VEC>(a.rq + (size_t)ad[i] * a.F + f, Q);
             }
+        bool frozen = false, stopped[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            stopped[v] = a.iters && a.iters[f + v] != 0;
+            frozen = frozen || stopped[v];
+        }
         if (a.D) {
             int d[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) d[v] = (S[v] < 0) ? 1 : 0;
-            vstore_i<VEC>(a.D + (size_t)n * a.F + f, d);
+            if (!frozen) vstore_i<VEC>(a.D + (size_t)n * a.F + f, d);
+            else {
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+                    if (!stopped[v]) a.D[(size_t)n * a.F + f + v] = d[v];
+            }
         }
-        if (a.app) vstore<VEC>(a.app + (size_t)n * a.F + f, S);
+        if (a.app) {
+            if (!frozen) vstore<VEC>(a.app + (size_t)n * a.F + f, S);
+            else {
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+                    if (!stopped[v]) a.app[(size_t)n * a.F + f + v] = S[v];
+            }
+        }
         if (a.bad && n < a.length) {
 #pragma unroll
             for (int v = 0; v < VEC; v++)
@@ -143,15 +163,21 @@ template <int VEC> __global__ __launch_bounds__(256) void k_table_cn(TableArgs a
 
 // Per-frame termination bookkeeping after one iteration (LDPC_Decoder.cu:134-153):
 //   flag = !bad; D[N][f] = flag; flag_hist bit; count frames whose flag is set; reset bad.
+// Per-frame exit (iters != nullptr): a running frame whose flag comes up, or that reaches the last iteration, records
+// `it` as its iteration count and stops; a stopped frame counts as flagged from then on.
 __global__ __launch_bounds__(256) void k_flags(int *bad, int *D_flag_row, unsigned long long *flag_hist, int *ok_count,
-                                               int F, int it)
+                                               int F, int it, int *iters, int last)
 {
     const int f = blockIdx.x * 256 + threadIdx.x;
     int flag = 0;
     if (f < F) {
         flag = bad[f] ? 0 : 1;
         bad[f] = 0;
-        if (D_flag_row) D_flag_row[f] = flag;
+        if (iters && iters[f] != 0) flag = 1; // stopped earlier: its flag row entry stays as written then
+        else {
+            if (D_flag_row) D_flag_row[f] = flag;
+            if (iters && (flag || last)) iters[f] = it;
+        }
         if (flag_hist && flag && it <= 64) flag_hist[f] |= (1ull << (it - 1));
     }
     if (ok_count) {
@@ -184,7 +210,8 @@ __global__ __launch_bounds__(256) void k_stat_errors(const int *D, const int *cw
         if (e[i]) atomicAdd(&errs[f + i], e[i]);
 }
 
-__global__ __launch_bounds__(256) void k_stat_final(int *errs, const int *flag_row, int F, int itera, long long *counters)
+__global__ __launch_bounds__(256) void k_stat_final(int *errs, const int *flag_row, int F, int itera, const int *iters,
+                                                    long long *counters)
 {
     const int f = blockIdx.x * 256 + threadIdx.x;
     long long v[5] = {0, 0, 0, 0, 0};
@@ -193,7 +220,7 @@ __global__ __launch_bounds__(256) void k_stat_final(int *errs, const int *flag_r
         errs[f] = 0; // leave the scratch zeroed for the next call
         v[0] = (err != 0 || flag == 0) ? 1 : 0; // num_Error_Frames
         v[1] = err;                              // num_Error_Bits
-        v[2] = itera;                            // Total_Iteration += iteraTime per frame (Simulation.cu:262)
+        v[2] = iters ? iters[f] : itera;         // Total_Iteration += iteraTime per frame (Simulation.cu:262)
         v[3] = (err != 0 && flag == 1) ? 1 : 0; // num_False_Frames
         v[4] = (err == 0 && flag == 0) ? 1 : 0; // num_Alarm_Frames
     }

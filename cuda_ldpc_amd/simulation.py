@@ -44,8 +44,13 @@ def Simulation_GPU(code, seed, sigma, SIM, Num_Frames_OneTime=4096, maxIT=50, ex
         if count:
             r = LDPC_Decoder_GPU(code, yd, max_iter=maxIT, length=length, exit_mode=exit_mode, kernel=kernel, D=D)
             st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, count, length, r["iteraTime"],
-                                      ctypes.c_void_p(dev_cnt.data_ptr()), st), "Statistic")
+            if r["iteraTime"] is None:  # EXIT_PER_FRAME: one iteration count per frame
+                check(lib.bldpc_statistic_per_frame(code._h, ctypes.c_void_p(D.data_ptr()), None, count, length,
+                                                    ctypes.c_void_p(r["iters"].data_ptr()), ctypes.c_void_p(dev_cnt.data_ptr()), st),
+                      "Statistic")
+            else:
+                check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, count, length, r["iteraTime"],
+                                          ctypes.c_void_p(dev_cnt.data_ptr()), st), "Statistic")
         sharding.allreduce_counters(dev_cnt, dist)
         c = dev_cnt.cpu().tolist()
         SIM.num_Error_Frames += c[0]

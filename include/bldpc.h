@@ -37,6 +37,8 @@ extern "C" {
 #define BLDPC_EXIT_FIXED 0        /* run exactly max_iter iterations (benchmark mode)                       */
 #define BLDPC_EXIT_BATCH_GLOBAL 1 /* reference rule: stop after the first iteration at which ALL F frames   */
                                   /* have their flag set (LDPC_Decoder.cu:150-153)                          */
+#define BLDPC_EXIT_PER_FRAME 2    /* the same rule applied to every frame on its own (what the reference does with  */
+                                  /* Num_Frames_OneTime = 1): bldpc_decode_per_frame only                           */
 
 /* kernel selection */
 #define BLDPC_KERNEL_AUTO 0   /* QC_LDS when the code has QC structure and fits LDS, else TABLE */
@@ -110,6 +112,18 @@ int bldpc_code_dims(const bldpc_code *code, int dims[8]);
 int bldpc_decode(bldpc_code *code, const float *Channel_Out, int F, int max_iter, int length, int exit_mode, int kernel,
                  int *D, float *app, unsigned long long *flag_hist, int *iteraTime, void *stream);
 
+/* Per-frame termination: frame f stops after the first iteration at which ITS flag is set -- the
+ * reference's rule (LDPC_Decoder.cu:134-153) as it acts on a batch of one frame -- and column f of D (and of app) holds
+ * the outputs of that iteration, exactly what LDPC_Decoder_GPU returns for that frame with Num_Frames_OneTime = 1;
+ * a frame whose flag never comes up runs max_iter iterations.  Nothing is recomputed and nothing waits for the slowest
+ * frame of the batch: on the fused kernels a workgroup leaves when its own (1-2) frames have stopped, so the cost of a
+ * batch follows the MEAN iteration count (BER sweeps at operating SNR: several times the fixed-iteration rate).
+ *   iters   device int32 [F]  (out) iterations executed by each frame (the reference's iteraTime of that frame)
+ * Other arguments as bldpc_decode.  Asynchronous on `stream` with the fused kernels; the table kernels read one
+ * counter per iteration, as for BATCH_GLOBAL. */
+int bldpc_decode_per_frame(bldpc_code *code, const float *Channel_Out, int F, int max_iter, int length, int kernel, int *D,
+                           float *app, int *iters, void *stream);
+
 /* Device-side Statistic (Simulation.cu:245-262) over one decoded batch against
  * the all-zero codeword (PN_Message 0, define.cuh:26) or CodeWord (device int32
  * [N][F], may be NULL = all-zero).  counters: device int64[5], ACCUMULATED:
@@ -117,6 +131,10 @@ int bldpc_decode(bldpc_code *code, const float *Channel_Out, int F, int max_iter
  *   [3] num_False_Frames [4] num_Alarm_Frames.   num_Frames is the caller's (+= F). */
 int bldpc_statistic(const bldpc_code *code, const int *D, const int *CodeWord, int F, int length, int iteraTime,
                     long long *counters, void *stream);
+
+/* The same with one iteration count per frame (bldpc_decode_per_frame): Total_Iteration += iters[f]. */
+int bldpc_statistic_per_frame(const bldpc_code *code, const int *D, const int *CodeWord, int F, int length, const int *iters,
+                              long long *counters, void *stream);
 
 /* Host input generator, bit-identical to the reference's (the "identical AWGN inputs" of the parity
  * contract): AWGNChannel_CPU + RandomModule (LDPC_Encoder.cu:25-56).  seed[3] is advanced in place

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--max-batches", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--fixed", action="store_true", help="fixed iteration count instead of the reference's batch-global early exit")
+    ap.add_argument("--per-frame", action="store_true", help="binary: every frame stops on its own flag (the reference rule with Num_Frames_OneTime = 1)")
     ap.add_argument("--method", type=int, default=0, choices=[0, 1, 2, 3], help="NB decoder_method (define.h:37): 0 EMS, 1 TMM, 2 log-QSPA, 3 layered TMM")
     ap.add_argument("--device-channel", action="store_true", help="generate the AWGN samples on the GPU (same RNG draws, device libm)")
     ap.add_argument("--as-written", action="store_true", help="decode on the reference's Transform_H table as written (SURVEY F3)")
@@ -59,10 +60,11 @@ def main():
             code = C.BinaryCode.from_blockh(args.matrix, args.J, args.L, args.Z)
         if rank == 0:
             print("# %s N=%d K=%d, %s, maxIT=%d, batch=%d x %d GPU(s)" % (os.path.basename(args.matrix), code.N, code.K,
-                  "fixed iterations" if args.fixed else "batch-global early exit", args.iters or 50, args.batch, world))
+                  "fixed iterations" if args.fixed else ("per-frame early exit" if args.per_frame else "batch-global early exit"),
+                  args.iters or 50, args.batch, world))
             print("# SNR      NTF   NEF         FER         BER  AverIT       FER_F      FER_A")
         sweep(code, args.start, args.stop, args.step, snrtype=1, dist=dist, Num_Frames_OneTime=args.batch, maxIT=args.iters or 50,
-              exit_mode=C.EXIT_FIXED if args.fixed else C.EXIT_BATCH_GLOBAL, max_batches=args.max_batches, displayStep=10 ** 12, device_channel=args.device_channel,
+              exit_mode=C.EXIT_FIXED if args.fixed else (C.EXIT_PER_FRAME if args.per_frame else C.EXIT_BATCH_GLOBAL), max_batches=args.max_batches, displayStep=10 ** 12, device_channel=args.device_channel,
               log=print if rank == 0 else None)
     else:
         from cuda_ldpc_amd import nbldpc as nb

@@ -414,3 +414,113 @@ def test_other_lifting_sizes_random_matrices(C, orc, tmp_path, Z, J, L):
     want = orc.bldpc_decode(ocode, y, F, 30, early_exit=1, want_app=True)
     got = _decode(C, code, y, F, max_iter=30, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
     _assert_same(got, want, code.N, F)
+
+
+# ---- per-frame termination (bldpc_decode_per_frame): the reference rule on batches of one frame -------------------------
+def _oracle_per_frame(orc, ocode, y, F, max_iter):
+    """LDPC_Decoder.cu:94-156 run on every frame alone (Num_Frames_OneTime = 1): D column, flag, iteraTime, sums per frame."""
+    N = ocode.N
+    yy = np.ascontiguousarray(y, np.float32).reshape(N, F)
+    D = np.zeros((N + 1, F), np.int32)
+    app = np.zeros((N, F), np.float32)
+    iters = np.zeros(F, np.int32)
+    for f in range(F):
+        w = orc.bldpc_decode(ocode, np.ascontiguousarray(yy[:, f]), 1, max_iter, early_exit=1, want_app=True)
+        D[:, f] = w["D"]
+        app[:, f] = w["app"]
+        iters[f] = w["it"]
+    return D, app, iters
+
+
+def _decode_per_frame(C, code, y, F, max_iter, kernel):
+    yt = torch.from_numpy(np.ascontiguousarray(y).reshape(code.N, F)).cuda()
+    r = C.LDPC_Decoder_GPU(code, yt, max_iter=max_iter, exit_mode=C.EXIT_PER_FRAME, kernel=kernel, want_app=True)
+    torch.cuda.synchronize()
+    return r["D"].cpu().numpy(), r["app"].cpu().numpy(), r["iters"].cpu().numpy(), r
+
+
+PER_FRAME_CODES = [("J4_L24_Z96_BlockH.txt", 4, 24, 96, 2.6, 37, 30), ("J32_L64_Z64_BlockH.txt", 32, 64, 64, -0.9, 21, 30),
+                   ("J4_L24_Z256_BlockH.txt", 4, 24, 256, 2.8, 9, 30), ("J10_L60_Z160_BlockH.txt", 10, 60, 160, 2.9, 5, 30),
+                   ("PON_LDPC.txt", 12, 69, 256, 2.3, 5, 30), ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, 0.1, 3, 30)]
+
+
+@pytest.mark.parametrize("fn,J,L,Z,snr,F,maxit", PER_FRAME_CODES)
+def test_per_frame_exit_matches_reference_rule_on_single_frames(C, orc, fn, J, L, Z, snr, F, maxit):
+    """Every frame stops on its own flag: hard bits, flag, a-posteriori sums and iteration count of each frame equal the
+    oracle's decode of that frame alone under the reference's early-exit rule -- on every kernel tier, ragged batches, with
+    frames that stop at different iterations inside one workgroup and frames that never stop."""
+    p = os.path.join(BL, fn)
+    y = _channel(orc, L * Z, F, snr)
+    ocode = orc.BinaryCode(p, J, L, Z)
+    code = C.BinaryCode.from_blockh(p, J, L, Z)
+    Dw, appw, itw = _oracle_per_frame(orc, ocode, y, F, maxit)
+    assert len(set(itw.tolist())) > 1, "pick an SNR at which frames stop at different iterations (%s)" % itw
+    for kern in (C.KERNEL_QC_LDS, C.KERNEL_TABLE):
+        D, app, it, _ = _decode_per_frame(C, code, y, F, maxit, kern)
+        assert np.array_equal(it, itw), "%s: iteration counts differ %s vs %s" % (code.last_kernel, it, itw)
+        assert np.array_equal(D, Dw), "%s: hard bits / flags differ" % code.last_kernel
+        assert np.array_equal(app.view(np.uint32), appw.view(np.uint32)), "%s: a-posteriori sums differ" % code.last_kernel
+
+
+def test_per_frame_exit_edge_cases(C, orc):
+    """max_iter = 1 and 2, a batch in which no frame ever stops, one in which every frame stops at iteration 1."""
+    J, L, Z = 4, 24, 96
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    for snr, F, maxit in ((2.6, 7, 1), (2.6, 7, 2), (-6.0, 6, 5), (12.0, 9, 8)):
+        y = _channel(orc, L * Z, F, snr)
+        Dw, appw, itw = _oracle_per_frame(orc, ocode, y, F, maxit)
+        for kern in (C.KERNEL_QC_LDS, C.KERNEL_TABLE):
+            D, app, it, _ = _decode_per_frame(C, code, y, F, maxit, kern)
+            assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
+    assert set(itw.tolist()) == {1}  # the last case: clean channel, hard decision of the channel values already passes
+    import ctypes
+    from cuda_ldpc_amd._lib import LdpcError, check, lib
+    with pytest.raises(LdpcError):  # the batch entry point has one iteration count: it refuses the per-frame mode
+        yt = torch.zeros((code.N, 4), device="cuda")
+        Dt = torch.zeros((code.N + 1, 4), dtype=torch.int32, device="cuda")
+        itc = ctypes.c_int(0)
+        check(lib.bldpc_decode(code._h, ctypes.c_void_p(yt.data_ptr()), 4, 5, 0, C.EXIT_PER_FRAME, 0, ctypes.c_void_p(Dt.data_ptr()), None, None,
+                               ctypes.byref(itc), None), "bldpc_decode")
+
+
+def test_per_frame_statistic_and_simulation_loop(C, orc):
+    """Statistic with one iteration count per frame, and the Simulation_GPU loop in per-frame mode, against the oracle's
+    Statistic fed frame by frame."""
+    J, L, Z, F = 4, 24, 96, 64
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    seed = np.array([173, 173, 173], np.int32)
+    y = orc.bldpc_awgn(seed, orc.bldpc_sigma(2.4), code.N, F)
+    Dw, _, itw = _oracle_per_frame(orc, ocode, y, F, 50)
+    cnt = np.zeros(5, np.int64)
+    for f in range(F):  # Statistic on batches of one frame (Simulation.cu:245-262)
+        orc.bldpc_statistic(cnt, f + 1, np.ascontiguousarray(Dw[:, f]), code.N, 1, code.K, int(itw[f]))
+    from cuda_ldpc_amd.simulation import Simulation_GPU
+    SIM = C.SimCounters()
+    Simulation_GPU(code, np.array([173, 173, 173], np.int32), orc.bldpc_sigma(2.4), SIM, Num_Frames_OneTime=F, maxIT=50,
+                   exit_mode=C.EXIT_PER_FRAME, max_batches=1, log=None)
+    assert [SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, SIM.num_False_Frames, SIM.num_Alarm_Frames] == list(cnt)
+    assert SIM.Total_Iteration == int(itw.sum()) and SIM.num_Frames == F
+
+
+def test_per_frame_exit_full_batch_properties(C, orc):
+    """65 536 frames at the benchmark point: iteration counts within [1, max_iter], flag <=> stopped early or passing at the last
+    iteration, and a sample of frames against the oracle."""
+    J, L, Z, F = 4, 24, 96, 65536
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    y0 = _channel(orc, L * Z, 4096, 3.0).reshape(code.N, 4096)
+    yt = torch.from_numpy(y0).cuda().repeat(1, F // 4096).contiguous()
+    r = C.LDPC_Decoder_GPU(code, yt, max_iter=50, exit_mode=C.EXIT_PER_FRAME)
+    torch.cuda.synchronize()
+    it = r["iters"].cpu().numpy()
+    flags = r["D"][code.N].cpu().numpy()
+    assert it.min() >= 1 and it.max() <= 50
+    assert np.all(flags[it < 50] == 1)
+    assert np.array_equal(it[:4096], it[4096:8192]) and np.array_equal(it[:4096], it[-4096:])  # tiled input, tiled result
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    pick = [0, 1, 77, 4095]
+    Dw, _, itw = _oracle_per_frame(orc, ocode, np.ascontiguousarray(y0[:, pick]), len(pick), 50)
+    D = r["D"].cpu().numpy()
+    for i, f in enumerate(pick):
+        assert it[f + 8192] == itw[i] and np.array_equal(D[:, f + 8192], Dw[:, i])
