@@ -25,7 +25,7 @@ struct bldpc_code {
     std::vector<int> level_begin; // node_list range of each VN level, size levels+1
     int *d_addr = nullptr, *d_node_list = nullptr;
     unsigned char *d_wv_blk = nullptr, *d_wc_blk = nullptr;
-    DevBuf rq, bad, cnt, bits, yg, errs;
+    DevBuf rq, bad, cnt, bits, yg, errs, itw;
     int *h_cnt = nullptr; // pinned
     QcPlan qc;            // fused LDS kernel description (frames_per_wg == 0: unavailable)
     const char *last_kernel = "none";
@@ -207,7 +207,7 @@ extern "C" int bldpc_code_destroy(bldpc_code *c)
     if (c->d_wv_blk) (void)hipFree(c->d_wv_blk);
     if (c->d_wc_blk) (void)hipFree(c->d_wc_blk);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-    c->rq.release(); c->bad.release(); c->cnt.release(); c->bits.release(); c->yg.release(); c->errs.release();
+    c->rq.release(); c->bad.release(); c->cnt.release(); c->bits.release(); c->yg.release(); c->errs.release(); c->itw.release();
     qc_plan_release(&c->qc);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -315,8 +315,9 @@ static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int l
         CLDPC_HIP(c->cnt.reserve(64), BLDPC_ENOMEM);
         CLDPC_HIP(c->bits.reserve((size_t)F * (c->N / 32) * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(c->yg.reserve(((size_t)F + 2) * c->N * sizeof(float)), BLDPC_ENOMEM);
+        if (exit_mode == BLDPC_EXIT_BATCH_GLOBAL) CLDPC_HIP(c->itw.reserve((size_t)F * sizeof(int)), BLDPC_ENOMEM);
         int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
-                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, iters, st,
+                          (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, iters, (int *)c->itw.p, st,
                           c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr);
         c->last_kernel = c->qc.name;
         return r;

@@ -889,6 +889,15 @@ __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist
     if ((threadIdx.x & 63) == 0) atomicAnd(out, x);
 }
 
+// Largest per-frame iteration count of a batch.
+__global__ __launch_bounds__(256) void k_iters_max(const int *iters, int F, int *out)
+{
+    int x = 0;
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < F; f += gridDim.x * 256) x = max(x, iters[f]);
+    for (int off = 32; off > 0; off >>= 1) x = max(x, __shfl_down(x, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, x);
+}
+
 // ---------------------------------------------------------------------------------------------
 using QcKernel = void (*)(QcArgs);
 struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; int U, CPT, regstate; };
@@ -1118,7 +1127,7 @@ inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStre
 // y here is the regrouped buffer produced by qc_regroup.
 inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
                      unsigned long long *hist, unsigned *bits, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                     int *iters = nullptr)
+                     int *iters = nullptr, bool expand = true)
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
@@ -1135,7 +1144,7 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     const int NW = q->L * q->Z / 32;
-    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW);
+    if (expand) hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW);
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
 }
@@ -1144,7 +1153,8 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 // yg: device float [ceil(F/NF)*NF][N] workspace for the regrouped channel values.
 inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
                      unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, unsigned *bits,
-                     float *yg, int *itera, int *iters, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+                     float *yg, int *itera, int *iters, int *iters_ws, hipStream_t st, hipEvent_t ev0 = nullptr,
+                     hipEvent_t ev1 = nullptr)
 {
     {
         int rr = qc_regroup(q, y, yg, F, st);
@@ -1159,24 +1169,42 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
         *itera = max_iter;
         return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters);
     }
-    // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are
-    // flagged.  Pass 1 runs max_iter iterations on-chip recording each frame's flag history; the AND of
-    // the histories gives that iteration; if it is earlier than max_iter, pass 2 replays exactly that many.
+    // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are flagged.  No
+    // workgroup can know that iteration while it runs, so it is found first and the batch then decoded with exactly that
+    // many iterations:
+    //   pass 1  per-frame exit (cheap: every workgroup leaves when its own frames are flagged) -> m = the latest
+    //           first-flag iteration of any frame (max_iter for a frame that never flags).  The batch cannot stop before m.
+    //   pass 2  `run` = m iterations with the flag history on: if every frame is flagged at some iteration <= run (usually
+    //           exactly at m) that is the stop iteration -- replayed if it is not `run` itself.  Otherwise a frame has lost
+    //           its flag again: double `run` and repeat; `run` = max_iter ends the search.
     if (max_iter > 64) return fail(BLDPC_EUNSUPPORTED, "QC_LDS with BATCH_GLOBAL exit supports max_iter <= 64 (got %d)", max_iter);
     unsigned long long *hist = flag_hist ? flag_hist : hist_ws;
-    int r = qc_launch(q, y, F, max_iter, length, D, app, hist, bits, st, ev0, ev1);
+    int r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false);
     if (r) return r;
-    CLDPC_HIP(hipMemsetAsync(and_ws, 0xFF, sizeof(unsigned long long), st), BLDPC_EHIP);
-    hipLaunchKernelGGL(k_hist_and, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, hist, F, and_ws);
-    unsigned long long all = 0;
-    CLDPC_HIP(hipMemcpyAsync(&all, and_ws, sizeof(all), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
+    int m = 0;
+    CLDPC_HIP(hipMemsetAsync(and_ws, 0, sizeof(unsigned long long), st), BLDPC_EHIP);
+    hipLaunchKernelGGL(k_iters_max, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, iters_ws, F, (int *)and_ws);
+    CLDPC_HIP(hipMemcpyAsync(&m, and_ws, sizeof(int), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
     CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
-    if (max_iter < 64) all &= ((1ull << max_iter) - 1);
-    int stop = max_iter;
-    if (all) stop = __builtin_ctzll(all) + 1;
-    *itera = stop;
-    if (stop < max_iter) return qc_launch(q, y, F, stop, length, D, app, flag_hist, bits, st);
-    return BLDPC_OK;
+    if (m < 1 || m > max_iter) return fail(BLDPC_EHIP, "per-frame pass returned iteration count %d", m);
+    for (int run = m;; run = std::min(max_iter, std::max(run + 4, 2 * run))) {
+        if ((r = qc_launch(q, y, F, run, length, D, app, hist, bits, st, ev0, ev1))) return r;
+        CLDPC_HIP(hipMemsetAsync(and_ws, 0xFF, sizeof(unsigned long long), st), BLDPC_EHIP);
+        hipLaunchKernelGGL(k_hist_and, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, hist, F, and_ws);
+        unsigned long long all = 0; // bit it-1: every frame flagged after iteration it
+        CLDPC_HIP(hipMemcpyAsync(&all, and_ws, sizeof(all), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
+        CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
+        if (run < 64) all &= ((1ull << run) - 1);
+        if (all) {
+            const int stop = __builtin_ctzll(all) + 1;
+            *itera = stop;
+            return stop < run ? qc_launch(q, y, F, stop, length, D, app, flag_hist, bits, st, ev0, ev1) : BLDPC_OK;
+        }
+        if (run == max_iter) {
+            *itera = max_iter;
+            return BLDPC_OK;
+        }
+    }
 }
 
 } // namespace cldpc

@@ -524,3 +524,22 @@ def test_per_frame_exit_full_batch_properties(C, orc):
     D = r["D"].cpu().numpy()
     for i, f in enumerate(pick):
         assert it[f + 8192] == itw[i] and np.array_equal(D[:, f + 8192], Dw[:, i])
+
+
+@pytest.mark.parametrize("snr,length,s0,stop_want", [(-3.0, 4, 194, 7), (-3.0, 8, 203, 40), (-2.0, 4, 188, 40)])
+def test_batch_global_when_a_frame_loses_its_flag_again(C, orc, snr, length, s0, stop_want):
+    """The fused kernels find the reference's stop iteration from a per-frame pass (latest first flag m), then decode m
+    iterations; when some frame is no longer flagged at m they must fall back to the full flag histories.  Short `length`
+    (few examined bits) at low SNR makes flags come and go: cases found with the oracle."""
+    J, L, Z, F = 4, 24, 96, 5
+    y = _channel(orc, L * Z, F, snr, seed=(s0, 173, 173))
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 40, early_exit=1, length=length, want_app=True)
+    assert want["it"] == stop_want
+    for kern in KERNELS:
+        got = _decode(C, code, y, F, max_iter=40, length=length, exit_mode=C.EXIT_BATCH_GLOBAL, kernel=_k(C, kern), want_app=True,
+                      want_flag_hist=True)
+        _assert_same(got, want, code.N, F)
+        mask = np.uint64((1 << want["it"]) - 1)
+        assert np.array_equal(got["flag_hist"] & mask, want["flag_hist"] & mask)
