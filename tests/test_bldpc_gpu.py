@@ -414,6 +414,9 @@ def test_other_lifting_sizes_random_matrices(C, orc, tmp_path, Z, J, L):
     want = orc.bldpc_decode(ocode, y, F, 30, early_exit=1, want_app=True)
     got = _decode(C, code, y, F, max_iter=30, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
     _assert_same(got, want, code.N, F)
+    Dw, appw, itw = _oracle_per_frame(orc, ocode, y, F, 30)  # and every frame on its own flag
+    D, app, it, _ = _decode_per_frame(C, code, y, F, 30, C.KERNEL_QC_LDS)
+    assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
 
 
 # ---- per-frame termination (bldpc_decode_per_frame): the reference rule on batches of one frame -------------------------
