@@ -304,6 +304,38 @@ extern "C" int nbldpc_demodulate_bpsk(const nbldpc_code *c, const float *rx, flo
     return NBLDPC_OK;
 }
 
+extern "C" int nbldpc_demodulate_qam(const nbldpc_code *c, const float *rx, const float *con, float sigma, int B, float *Lch, void *stream)
+{
+    if (!c || !rx || !con || !Lch || B <= 0 || !(sigma > 0)) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_qam: bad argument");
+    const size_t total = (size_t)B * c->N * (c->q - 1);
+    hipLaunchKernelGGL(k_nb_demod_qam, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rx, con, sigma, B, c->N,
+                       c->q, Lch);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_read_constellation(const char *path, int n_points, float *con)
+{
+    if (!path || !con || n_points <= 0) return fail(NBLDPC_EINVAL, "nbldpc_read_constellation: bad argument");
+    FILE *fp = fopen(path, "r");
+    if (!fp) return fail(NBLDPC_EIO, "can not open file: %s", path);
+    char tmp[100];
+    for (int k = 0; k < n_points; k++) { // "Point: <idx> Real: <x> Imag: <y>" (Simulation.cpp:326-334)
+        int idx = -1;
+        float re = 0, im = 0;
+        const bool ok = fscanf(fp, "%99s", tmp) == 1 && fscanf(fp, "%d", &idx) == 1 && fscanf(fp, "%99s", tmp) == 1 && fscanf(fp, "%f", &re) == 1 &&
+                        fscanf(fp, "%99s", tmp) == 1 && fscanf(fp, "%f", &im) == 1;
+        if (!ok || idx < 0 || idx >= n_points) {
+            fclose(fp);
+            return fail(NBLDPC_EIO, "%s: record %d is not 'Point: <0..%d> Real: <x> Imag: <y>'", path, k, n_points - 1);
+        }
+        con[2 * idx] = re;
+        con[2 * idx + 1] = im;
+    }
+    fclose(fp);
+    return NBLDPC_OK;
+}
+
 extern "C" int nbldpc_statistic(const nbldpc_code *c, const int *out, const int *iters, const int *ok, const int *cw, int B,
                                 long long *counters, void *stream)
 {
@@ -336,6 +368,21 @@ extern "C" int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *cw,
         rx[i] = (float)((double)sigma * std::cos(two_pi * (double)u2) * (double)amp + (double)tx);
         (void)random_module(seed); // the Image part draws two more numbers (LDPC_Encoder.cpp:62-66)
         (void)random_module(seed);
+    }
+    return NBLDPC_OK;
+}
+
+extern "C" int nbldpc_awgn_channel_host_qam(int seed[3], float sigma, const int *cw, int N, const float *con, int n_points, float *rx)
+{
+    if (!seed || !cw || !con || !rx || N <= 0 || n_points <= 0) return fail(NBLDPC_EINVAL, "nbldpc_awgn_channel_host_qam: bad argument");
+    const double two_pi = 2 * 3.1415926; // define.h:56
+    for (int i = 0; i < N; i++) {
+        if (cw[i] < 0 || cw[i] >= n_points) return fail(NBLDPC_EINVAL, "CodeWord_sym[%d]=%d outside the constellation", i, cw[i]);
+        for (int c = 0; c < 2; c++) { // Real, then Image: two draws each (LDPC_Encoder.cpp:56-66), Modulate :22-26
+            float u1 = random_module(seed), u2 = random_module(seed);
+            const float amp = std::sqrt(-2.0f * std::log(1.0f - u1));
+            rx[2 * i + c] = (float)((double)sigma * std::cos(two_pi * (double)u2) * (double)amp + (double)con[2 * cw[i] + c]);
+        }
     }
     return NBLDPC_OK;
 }
@@ -394,6 +441,50 @@ extern "C" int nbldpc_awgn_channel_device(int seed[3], float sigma, const int *c
                        (unsigned)seed[2], sigma, cw, N, m, B, rx);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     const unsigned long long draws = 4ull * (unsigned long long)N * m * B;
+    for (int i = 0; i < 3; i++) seed[i] = (int)(((unsigned long long)seed[i] * nb_powmod(kNbA[i], draws, kNbM[i])) % kNbM[i]);
+    return NBLDPC_OK;
+}
+
+namespace {
+// QAM: one thread per (frame b, symbol i): jump to draw 4*(b*N + i), Real part from draws 1-2, Image part from draws 3-4.
+__global__ __launch_bounds__(256) void k_nb_awgn_qam(unsigned s0, unsigned s1, unsigned s2, float sigma, const int *cw, const float *con, int N, int B,
+                                                    float *rx)
+{
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)B * N) return;
+    const int i = (int)(id % N);
+    unsigned s[3] = {s0, s1, s2};
+#pragma unroll
+    for (int j = 0; j < 3; j++) s[j] = (unsigned)(((unsigned long long)s[j] * nb_powmod(kNbA[j], 4ull * (unsigned long long)id, kNbM[j])) % kNbM[j]);
+    const double two_pi = 2 * 3.1415926; // define.h:56
+    float u[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) s[j] = (s[j] * kNbA[j]) % kNbM[j];
+        float t = ((float)(int)s[0] / 61967.0f) + ((float)(int)s[1] / 63443.0f) + ((float)(int)s[2] / 63599.0f);
+        t -= (int)t;
+        u[d] = t;
+    }
+    const int sym = cw[i];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const float amp = sqrtf(-2.0f * logf(1.0f - u[2 * c]));
+        rx[2 * id + c] = (float)((double)sigma * cos(two_pi * (double)u[2 * c + 1]) * (double)amp + (double)con[2 * sym + c]);
+    }
+}
+} // namespace
+
+extern "C" int nbldpc_awgn_channel_device_qam(int seed[3], float sigma, const int *cw, int N, const float *con, int B, float *rx, void *stream)
+{
+    if (!seed || !cw || !con || !rx || N <= 0 || B <= 0) return fail(NBLDPC_EINVAL, "nbldpc_awgn_channel_device_qam: bad argument");
+    for (int i = 0; i < 3; i++)
+        if (seed[i] < 0 || (unsigned)seed[i] >= kNbM[i]) return fail(NBLDPC_EINVAL, "seed[%d]=%d outside [0,%u)", i, seed[i], kNbM[i]);
+    const long long threads = (long long)B * N;
+    hipLaunchKernelGGL(k_nb_awgn_qam, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned)seed[0],
+                       (unsigned)seed[1], (unsigned)seed[2], sigma, cw, con, N, B, rx);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    const unsigned long long draws = 4ull * (unsigned long long)N * B;
     for (int i = 0; i < 3; i++) seed[i] = (int)(((unsigned long long)seed[i] * nb_powmod(kNbA[i], draws, kNbM[i])) % kNbM[i]);
     return NBLDPC_OK;
 }

@@ -528,6 +528,20 @@ __global__ __launch_bounds__(256) void k_nb_demod_bpsk(const float *rx, float si
     Lch[id] = acc;
 }
 
+// Demodulate, n_QAM != 2 branch (LDPC_Decoder.cpp:160-169): one received point per code symbol, float arithmetic in the
+// reference's order.  rx [B][N][2] (Real, Image), con [q][2].
+__global__ __launch_bounds__(256) void k_nb_demod_qam(const float *rx, const float *con, float sigma, int B, int N, int q, float *Lch)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * N * (q - 1);
+    if (id >= total) return;
+    const int k = (int)(id % (q - 1)) + 1;
+    const size_t bs = id / (q - 1); // b*N + s
+    const float yr = rx[2 * bs], yi = rx[2 * bs + 1];
+    const float c0r = con[0], c0i = con[1], ckr = con[2 * k], cki = con[2 * k + 1];
+    Lch[id] = ((2 * yr - c0r - ckr) * (ckr - c0r) + (2 * yi - c0i - cki) * (cki - c0i)) / (2 * sigma * sigma);
+}
+
 // Statistic (Simulation.cpp:256-279): one thread per frame.
 __global__ __launch_bounds__(256) void k_nb_statistic(const int *out, const int *iters, const int *ok, const int *cw, int B, int N,
                                                       long long *counters)

@@ -25,6 +25,10 @@ lib.nbldpc_demodulate_bpsk.argtypes = [c_void_p, c_void_p, c_float, c_int, c_voi
 lib.nbldpc_statistic.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
 lib.nbldpc_awgn_channel_host.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]
 lib.nbldpc_awgn_channel_device.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+lib.nbldpc_read_constellation.argtypes = [c_char_p, c_int, c_void_p]
+lib.nbldpc_awgn_channel_host_qam.argtypes = [c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]
+lib.nbldpc_awgn_channel_device_qam.argtypes = [c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
+lib.nbldpc_demodulate_qam.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]
 lib.nbldpc_sigma.restype = c_float
 lib.nbldpc_sigma.argtypes = [c_float, c_int, c_int, c_float]
 
@@ -132,8 +136,27 @@ def Decoding_TMM(code, L_ch, maxIT=20, layered=False, want_state=False, stream=N
     return dict(DecodeOutput=out, iter_number=iters, ok=ok, LLR=LLR, L_c2v=c2v)
 
 
-def Demodulate(code, rx, sigma, stream=None):
-    """Demodulate, BPSK branch (LDPC_Decoder.cpp:132-157), on the device: rx [B, N*m] -> L_ch [B, N, q-1]."""
+def Get_CONSTELLATION(path, n_QAM):
+    """Get_CONSTELLATION (Simulation.cpp:313-338) -> host float32 [n_QAM, 2] (Real, Image)."""
+    con = np.zeros((n_QAM, 2), np.float32)
+    _check(lib.nbldpc_read_constellation(str(path).encode(), n_QAM, _np(con)), "Get_CONSTELLATION")
+    return con
+
+
+def Demodulate(code, rx, sigma, stream=None, CONSTELLATION=None):
+    """Demodulate on the device.  BPSK branch (LDPC_Decoder.cpp:132-157): rx [B, N*m] -> L_ch [B, N, q-1].  With
+    CONSTELLATION (CUDA float32 [q, 2]) the n_QAM != 2 branch (:160-169): rx [B, N, 2] (parity unpinned, include/nbldpc.h)."""
+    if CONSTELLATION is not None:
+        if not (rx.is_cuda and rx.dtype == torch.float32 and rx.is_contiguous() and rx.dim() == 3 and tuple(rx.shape[1:]) == (code.N, 2)):
+            raise ValueError("rx must be a contiguous CUDA float32 tensor [B, N, 2]")
+        if not (CONSTELLATION.is_cuda and CONSTELLATION.dtype == torch.float32 and CONSTELLATION.is_contiguous()
+                and tuple(CONSTELLATION.shape) == (code.q, 2)):
+            raise ValueError("CONSTELLATION must be a contiguous CUDA float32 tensor [q, 2]")
+        B = int(rx.shape[0])
+        Lch = torch.empty((B, code.N, code.q - 1), dtype=torch.float32, device=rx.device)
+        st = c_void_p((stream or torch.cuda.current_stream(rx.device)).cuda_stream)
+        _check(lib.nbldpc_demodulate_qam(code._h, _dev(rx), _dev(CONSTELLATION), c_float(sigma), B, _dev(Lch), st), "Demodulate")
+        return Lch
     if not (rx.is_cuda and rx.dtype == torch.float32 and rx.is_contiguous() and rx.dim() == 2 and rx.shape[1] == code.N * code.m):
         raise ValueError("rx must be a contiguous CUDA float32 tensor [B, N*m]")
     B = int(rx.shape[0])
@@ -143,17 +166,23 @@ def Demodulate(code, rx, sigma, stream=None):
     return Lch
 
 
-def AWGNChannel_CPU(seed, sigma, code, CodeWord_sym):
-    """Modulate (BPSK) + AWGNChannel_CPU (LDPC_Encoder.cpp:18-68) for ONE frame -> host rx [N*m]; seed advanced."""
+def AWGNChannel_CPU(seed, sigma, code, CodeWord_sym, CONSTELLATION=None):
+    """Modulate + AWGNChannel_CPU (LDPC_Encoder.cpp:18-68) for ONE frame; seed advanced.  BPSK -> host rx [N*m]; with
+    CONSTELLATION (host float32 [q, 2]) the n_QAM != 2 branch -> host rx [N, 2]."""
     if not (isinstance(seed, np.ndarray) and seed.dtype == np.int32 and seed.size == 3):
         raise ValueError("seed must be an int32 numpy array of 3")
     cw = np.ascontiguousarray(CodeWord_sym, np.int32)
+    if CONSTELLATION is not None:
+        con = np.ascontiguousarray(CONSTELLATION, np.float32)
+        rx = np.empty((code.N, 2), np.float32)
+        _check(lib.nbldpc_awgn_channel_host_qam(_np(seed), c_float(sigma), _np(cw), code.N, _np(con), con.shape[0], _np(rx)), "AWGNChannel_CPU")
+        return rx
     rx = np.empty(code.N * code.m, np.float32)
     _check(lib.nbldpc_awgn_channel_host(_np(seed), c_float(sigma), _np(cw), code.N, code.m, _np(rx)), "AWGNChannel_CPU")
     return rx
 
 
-def AWGNChannel_GPU(seed, sigma, code, CodeWord_sym_dev, B, stream=None):
+def AWGNChannel_GPU(seed, sigma, code, CodeWord_sym_dev, B, stream=None, CONSTELLATION=None):
     """Device-side Modulate + AWGNChannel for B consecutive frames of the same stream (LCG jump-ahead: the uniforms are
     the reference's, the samples may differ from the host libm's by an ulp).  Returns rx CUDA float32 [B, N*m]; seed
     advanced exactly like B calls of AWGNChannel_CPU."""
@@ -161,16 +190,25 @@ def AWGNChannel_GPU(seed, sigma, code, CodeWord_sym_dev, B, stream=None):
         raise ValueError("seed must be an int32 numpy array of 3")
     if not (CodeWord_sym_dev.is_cuda and CodeWord_sym_dev.dtype == torch.int32 and CodeWord_sym_dev.numel() == code.N):
         raise ValueError("CodeWord_sym_dev must be a CUDA int32 tensor of N symbols")
+    if CONSTELLATION is not None:  # n_QAM != 2 branch: rx [B, N, 2], four draws per SYMBOL
+        if not (CONSTELLATION.is_cuda and CONSTELLATION.dtype == torch.float32 and CONSTELLATION.is_contiguous()
+                and tuple(CONSTELLATION.shape) == (code.q, 2)):
+            raise ValueError("CONSTELLATION must be a contiguous CUDA float32 tensor [q, 2]")
+        rx = torch.empty((B, code.N, 2), dtype=torch.float32, device=CodeWord_sym_dev.device)
+        st = c_void_p((stream or torch.cuda.current_stream(rx.device)).cuda_stream)
+        _check(lib.nbldpc_awgn_channel_device_qam(_np(seed), c_float(sigma), _dev(CodeWord_sym_dev), code.N, _dev(CONSTELLATION), B, _dev(rx), st),
+               "AWGNChannel_GPU")
+        return rx
     rx = torch.empty((B, code.N * code.m), dtype=torch.float32, device=CodeWord_sym_dev.device)
     st = c_void_p((stream or torch.cuda.current_stream(rx.device)).cuda_stream)
     _check(lib.nbldpc_awgn_channel_device(_np(seed), c_float(sigma), _dev(CodeWord_sym_dev), code.N, code.m, B, _dev(rx), st), "AWGNChannel_GPU")
     return rx
 
 
-def seed_after(seed, frames, code):
-    """The RandomModule state after `frames` more frames (4 draws per bit): what the reference's seed would be."""
+def seed_after(seed, frames, code, qam=False):
+    """The RandomModule state after `frames` more frames (4 draws per bit; per symbol with a QAM constellation)."""
     a, m = (249, 251, 252), (61967, 63443, 63599)
-    k = 4 * code.N * code.m * int(frames)
+    k = 4 * code.N * (1 if qam else code.m) * int(frames)
     return np.array([(int(seed[i]) * pow(a[i], k, m[i])) % m[i] for i in range(3)], np.int32)
 
 

@@ -102,6 +102,30 @@ int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *CodeWord_sym, 
  * like B calls of nbldpc_awgn_channel_host. */
 int nbldpc_awgn_channel_device(int seed[3], float sigma, const int *CodeWord_sym, int N, int m, int B, float *rx, void *stream);
 
+/* ---- QAM constellations (n_QAM != 2 branches; n_QAM = q: one constellation point per code symbol).  PARITY UNPINNED: the
+ * reference's define.h:25 fixes n_QAM 2, its tree holds no output of these branches and the reference build under oracle/_ref
+ * cannot run them; they follow the source text and are checked against the restatement in oracle/nbldpc_oracle.c only. ---- */
+
+/* Replaces Get_CONSTELLATION (src/Simulation.cpp:313-338): n_points records "Point: <idx> Real: <x> Imag: <y>" ->
+ * constellation HOST float [n_points][2] (Real, Image), indexed by the record's own idx. */
+int nbldpc_read_constellation(const char *path, int n_points, float *constellation);
+
+/* Modulate (src/LDPC_Encoder.cpp:18-28: symbol s -> CONSTELLATION[CodeWord_sym[s]]) + AWGNChannel_CPU with
+ * len = Variablenode_num (:41-68: two draws for the Real part, two for the Image part, cos branch).
+ * rx: HOST float [N][2] for ONE frame; seed[3] advanced in place. */
+int nbldpc_awgn_channel_host_qam(int seed[3], float sigma, const int *CodeWord_sym, int N, const float *constellation, int n_points,
+                                 float *rx);
+
+/* The same for B consecutive frames on the device (LCG jump-ahead per symbol, device libm as nbldpc_awgn_channel_device).
+ * CodeWord_sym: DEVICE int32 [N]; constellation: DEVICE float [q][2]; rx: DEVICE float [B][N][2]. */
+int nbldpc_awgn_channel_device_qam(int seed[3], float sigma, const int *CodeWord_sym, int N, const float *constellation, int B, float *rx,
+                                   void *stream);
+
+/* Replaces Demodulate, n_QAM != 2 branch (src/LDPC_Decoder.cpp:160-169), on the device:
+ * rx float [B][N][2], constellation DEVICE float [q][2] -> L_ch float [B][N][q-1]. */
+int nbldpc_demodulate_qam(const nbldpc_code *code, const float *rx, const float *constellation, float sigma, int B, float *L_ch,
+                          void *stream);
+
 /* sigma of a sweep point (src/main.cu:221-228). */
 float nbldpc_sigma(float SNR, int snrtype, int n_QAM, float rate);
 

@@ -47,6 +47,9 @@ def lib():
         L.orc_bldpc_statistic.argtypes = [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]
         L.orc_nb_awgn.argtypes = [c_void_p, c_float, c_void_p, c_void_p, c_int]
         L.orc_nb_demodulate_bpsk.argtypes = [c_void_p, c_float, c_int, c_int, c_int, c_void_p]
+        L.orc_nb_read_constellation.argtypes = [ctypes.c_char_p, c_int, c_void_p]
+        L.orc_nb_awgn_qam.argtypes = [c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]
+        L.orc_nb_demodulate_qam.argtypes = [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]
         _LIB = L
     return _LIB
 
@@ -165,6 +168,32 @@ def nb_channel(code, cw_sym, seed, sigma):
     rx = np.zeros(code.N * code.m, np.float32)
     lib().orc_nb_awgn(_p(seed), c_float(sigma), _p(tx), _p(rx), code.N * code.m)
     return rx, nb_demodulate(code, rx, sigma)
+
+
+def nb_read_constellation(path, n_points):
+    """Get_CONSTELLATION -> float32 [n_points, 2] (Real, Image)."""
+    con = np.zeros((n_points, 2), np.float32)
+    r = lib().orc_nb_read_constellation(str(path).encode(), n_points, _p(con))
+    if r != 0:
+        raise IOError("orc_nb_read_constellation(%s) -> %d" % (path, r))
+    return con
+
+
+def nb_channel_qam(code, cw_sym, seed, sigma, con):
+    """QAM branch (parity unpinned, see nbldpc_oracle.c): Modulate + AWGNChannel_CPU + Demodulate -> (rx [N,2], Lch [N][q-1])."""
+    cw = np.ascontiguousarray(cw_sym, np.int32)
+    con = np.ascontiguousarray(con, np.float32)
+    rx = np.zeros((code.N, 2), np.float32)
+    lib().orc_nb_awgn_qam(_p(seed), c_float(sigma), _p(cw), code.N, _p(con), _p(rx))
+    return rx, nb_demodulate_qam(code, rx, sigma, con)
+
+
+def nb_demodulate_qam(code, rx, sigma, con):
+    rx = np.ascontiguousarray(rx, np.float32)
+    con = np.ascontiguousarray(con, np.float32)
+    Lch = np.zeros((code.N, code.q - 1), np.float32)
+    lib().orc_nb_demodulate_qam(_p(rx), _p(con), c_float(sigma), code.N, code.q, _p(Lch))
+    return Lch
 
 
 def nb_demodulate(code, rx, sigma):

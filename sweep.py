@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--fixed", action="store_true", help="fixed iteration count instead of the reference's batch-global early exit")
     ap.add_argument("--per-frame", action="store_true", help="binary: every frame stops on its own flag (the reference rule with Num_Frames_OneTime = 1)")
+    ap.add_argument("--qam", type=int, default=2, choices=[2, 64], help="nb: n_QAM (define.h:25): 2 = BPSK, 64 = Constellation/GRAY_64QAM.txt, one point per GF(64) symbol")
     ap.add_argument("--method", type=int, default=0, choices=[0, 1, 2, 3], help="NB decoder_method (define.h:37): 0 EMS, 1 TMM, 2 log-QSPA, 3 layered TMM")
     ap.add_argument("--device-channel", action="store_true", help="generate the AWGN samples on the GPU (same RNG draws, device libm)")
     ap.add_argument("--as-written", action="store_true", help="decode on the reference's Transform_H table as written (SURVEY F3)")
@@ -73,12 +74,14 @@ def main():
         mul, _, _ = nb.GFInitial(64, os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
         code = nb.NBCode(os.path.join(nbd, "BDS.576.288.GF.64.txt"), mul)
         cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
-        print("# BDS.576.288.GF.64 N=%d symbols GF(%d), %s, maxIT=%d" % (code.N, code.q, ["EMS(2,2)", "trellis min-max", "log-QSPA = EMS(q,dc-1)", "layered trellis min-max"][args.method], args.iters or 20))
+        con = None if args.qam == 2 else nb.Get_CONSTELLATION(os.path.join(nbd, "Constellation", "GRAY_64QAM.txt"), args.qam)
+        print("# BDS.576.288.GF.64 N=%d symbols GF(%d), %s, maxIT=%d, %s" % (code.N, code.q, ["EMS(2,2)", "trellis min-max", "log-QSPA = EMS(q,dc-1)", "layered trellis min-max"][args.method], args.iters or 20,
+              "BPSK" if args.qam == 2 else "%d-QAM (Gray), one point per symbol" % args.qam))
         print("# SNR      NTF   NEF         FER         BER  AverIT")
         nbatch = args.batch if args.device_channel else min(args.batch, 1024)  # the host channel is serial: keep its batches small
         sweep(code, cw, args.start, args.stop, args.step, maxIT=args.iters or 20, batch=nbatch,
               max_frames=None if args.max_batches is None else args.max_batches * nbatch, device_channel=args.device_channel,
-              decoder_method=args.method)
+              decoder_method=args.method, n_QAM=args.qam, CONSTELLATION=con)
     if world > 1:
         dist.destroy_process_group()
 

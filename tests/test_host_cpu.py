@@ -180,3 +180,33 @@ def test_division_shortcut_exhaustive(tmp_path):
     subprocess.check_call([gcc, "-O2", "-fopenmp", "-ffp-contract=off", src, "-lm", "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert "checked 4278190078 floats, 0 mismatches" in out, out
+
+
+def test_qam_constellation_and_channel_equal_the_restatement(nbm, orc):
+    """n_QAM != 2 branches (PARITY UNPINNED against the reference: its define.h fixes n_QAM = 2 and its tree holds no output of
+    these branches): the library's reader and host channel equal the oracle's restatement of Get_CONSTELLATION / Modulate /
+    AWGNChannel_CPU bit for bit, seeds included; the shipped 64-QAM file is a unit-energy Gray-labelled square grid."""
+    path = os.path.join(NB, "Constellation", "GRAY_64QAM.txt")
+    con = nbm.Get_CONSTELLATION(path, 64)
+    assert np.array_equal(con, orc.nb_read_constellation(path, 64))
+    assert len({(float(a), float(b)) for a, b in con}) == 64 and abs(float((con.astype(np.float64) ** 2).sum(1).mean()) - 1.0) < 1e-6
+    lv = np.unique(np.round(con[:, 0], 6))
+    assert len(lv) == 8 and np.allclose(np.diff(lv), lv[1] - lv[0], atol=1e-6)
+    step = float(lv[1] - lv[0])
+    for a in range(64):  # Gray labelling: nearest neighbours differ in exactly one bit
+        for b in range(64):
+            if a < b and abs(float(np.hypot(*(con[a] - con[b]))) - step) < 1e-4:
+                assert bin(a ^ b).count("1") == 1
+
+    class Shape:
+        N, m, q = 96, 6, 64
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    sigma = nbm.sigma_of(9.0, 0.5, 0, 64)
+    assert np.float32(sigma) == np.float32(orc.nb_sigma(9.0, 0.5, 0, 64))
+    s1, s2 = np.array([173, 173, 173], np.int32), np.array([173, 173, 173], np.int32)
+    for _ in range(3):
+        rx = nbm.AWGNChannel_CPU(s1, sigma, Shape, cw, CONSTELLATION=con)
+        want, _ = orc.nb_channel_qam(Shape, cw, s2, sigma, con)
+        assert rx.shape == (96, 2) and np.array_equal(rx.view(np.uint32), want.view(np.uint32)) and np.array_equal(s1, s2)
+    with pytest.raises(Exception):
+        nbm.Get_CONSTELLATION(os.path.join(NB, "Constellation", "BPSK.txt"), 64)  # two records only

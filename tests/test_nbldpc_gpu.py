@@ -389,3 +389,70 @@ def test_reference_signature_shim_cpp_harness(nb, code, orc, tmp_path, method, t
         want = "frame %d ok=%d it=%d out=%08x LLR=%08x c2v=%08x" % (fr, int(g["ok"][fr]), int(g["it"][fr]), orc.fold_hash(g["out"][fr]),
                                                                     int(g["LLR_hash"][fr]), int(g["c2v_hash"][fr]))
         assert line == want, (line, want)
+
+
+# ---- QAM constellations (n_QAM = q).  PARITY UNPINNED against the reference (define.h fixes n_QAM = 2; nothing in its tree
+# records an output of these branches): the checker is the oracle's restatement of the source text. -----------------------------
+@pytest.fixture(scope="module")
+def qam64(nb):
+    return nb.Get_CONSTELLATION(os.path.join(NB, "Constellation", "GRAY_64QAM.txt"), 64)
+
+
+def test_qam_demodulate_and_decode_vs_oracle(nb, code, ocode, orc, qam64):
+    """Demodulate (n_QAM != 2 branch) on the device equals the restatement bit for bit; the decoders then see the same
+    L_ch and agree with the oracle as for BPSK (EMS and trellis min-max), frames that converge and frames that do not."""
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    con_dev = torch.from_numpy(qam64).cuda()
+    for snr, B in ((11.0, 6), (14.0, 6)):  # the waterfall of this code with 64-QAM and EMS(2,2) is near Eb/N0 = 11-12 dB
+        sigma = nb.sigma_of(snr, code.rate, 0, 64)
+        seed = np.array([173, 173, 173], np.int32)
+        rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, cw, CONSTELLATION=qam64) for _ in range(B)])
+        Lch = nb.Demodulate(code, torch.from_numpy(rx).cuda(), sigma, CONSTELLATION=con_dev)
+        want_L = np.stack([orc.nb_demodulate_qam(ocode, rx[b], sigma, qam64) for b in range(B)])
+        assert np.array_equal(Lch.cpu().numpy().view(np.uint32), want_L.view(np.uint32))
+        r = nb.Decoding_EMS(code, Lch, 2, 2, 20, want_state=True)
+        t = nb.Decoding_TMM(code, Lch, 20, layered=False)
+        torch.cuda.synchronize()
+        for b in range(B):
+            w = orc.nb_ems_decode(ocode, want_L[b], 2, 2, 20, want_state=True)
+            assert int(r["iter_number"][b]) == w["it"] and int(r["ok"][b]) == w["ok"]
+            assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), w["out"])
+            assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), w["LLR"].view(np.uint32))
+            wt = orc.nb_tmm_decode(ocode, want_L[b], 20, layered=False)
+            assert int(t["iter_number"][b]) == wt["it"] and np.array_equal(t["DecodeOutput"][b].cpu().numpy(), wt["out"])
+    assert all(int(x) == 1 for x in r["ok"]) and np.array_equal(r["DecodeOutput"].cpu().numpy(), np.tile(cw, (B, 1)))  # 14 dB: all decode
+
+
+def test_qam_device_channel_and_simulation_loop(nb, code, ocode, orc, qam64):
+    """Device-side QAM channel: same draws as the host loop (seeds equal, samples equal up to the device libm); the simulation
+    loop with a constellation stops where a per-frame replay with the oracle stops."""
+    from cuda_ldpc_amd.nb_simulation import NBSim, Simulation_GPU
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    con_dev = torch.from_numpy(qam64).cuda()
+    sigma = nb.sigma_of(12.0, code.rate, 0, 64)
+    s_host, s_dev = np.array([173, 173, 173], np.int32), np.array([173, 173, 173], np.int32)
+    B = 11
+    rx_h = np.stack([nb.AWGNChannel_CPU(s_host, sigma, code, cw, CONSTELLATION=qam64) for _ in range(B)])
+    rx_d = nb.AWGNChannel_GPU(s_dev, sigma, code, torch.from_numpy(cw).cuda(), B, CONSTELLATION=con_dev).cpu().numpy()
+    assert np.array_equal(s_host, s_dev) and rx_d.shape == (B, 96, 2)
+    same = (rx_h.view(np.int32) == rx_d.view(np.int32)).mean()
+    assert same > 0.8 and np.abs(rx_h - rx_d).max() < 1e-6, (same, np.abs(rx_h - rx_d).max())
+    assert np.array_equal(nb.seed_after(np.array([173, 173, 173], np.int32), B, code, qam=True), s_host)
+    snr = 11.5
+    sigma = nb.sigma_of(snr, code.rate, 0, 64)
+    seed = np.array([173, 173, 173], np.int32)
+    SIM = NBSim(snr)
+    stop = Simulation_GPU(code, seed, sigma, SIM, cw, batch=64, leastErrorFrames=6, leastTestFrames=20, CONSTELLATION=qam64)
+    assert stop == 1
+    oseed = np.array([173, 173, 173], np.int32)
+    frames = errf = errb = its = 0
+    while errf < 6 or frames < 20:
+        _, Lch = orc.nb_channel_qam(ocode, cw, oseed, sigma, qam64)
+        r = orc.nb_ems_decode(ocode, Lch, 2, 2, 20)
+        frames += 1
+        its += r["it"]
+        e = int((r["out"] != cw).sum())
+        errb += e
+        errf += 1 if e else 0
+    assert (SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration) == (frames, errf, errb, its)
+    assert np.array_equal(seed, oseed)
