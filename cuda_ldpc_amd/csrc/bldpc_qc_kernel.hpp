@@ -978,6 +978,7 @@ struct QcPlan {
     unsigned *d_cn_meta = nullptr, *d_vn_meta = nullptr; // compressed-state kernel
     int WVS = 0, lds_bytes = 0, lc = 0;
     char name[96] = "qc_lds(unavailable)";
+    mutable int ran_to_max = 0; // BATCH_GLOBAL: the previous batch did not stop before max_iter (a performance hint, never a result)
 };
 
 inline void qc_plan_release(QcPlan *q)
@@ -1179,29 +1180,42 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     //           its flag again: double `run` and repeat; `run` = max_iter ends the search.
     if (max_iter > 64) return fail(BLDPC_EUNSUPPORTED, "QC_LDS with BATCH_GLOBAL exit supports max_iter <= 64 (got %d)", max_iter);
     unsigned long long *hist = flag_hist ? flag_hist : hist_ws;
-    int r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false);
-    if (r) return r;
-    int m = 0;
-    CLDPC_HIP(hipMemsetAsync(and_ws, 0, sizeof(unsigned long long), st), BLDPC_EHIP);
-    hipLaunchKernelGGL(k_iters_max, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, iters_ws, F, (int *)and_ws);
-    CLDPC_HIP(hipMemcpyAsync(&m, and_ws, sizeof(int), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
-    CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
-    if (m < 1 || m > max_iter) return fail(BLDPC_EHIP, "per-frame pass returned iteration count %d", m);
-    for (int run = m;; run = std::min(max_iter, std::max(run + 4, 2 * run))) {
-        if ((r = qc_launch(q, y, F, run, length, D, app, hist, bits, st, ev0, ev1))) return r;
+    // A batch that holds a frame which never passes costs the per-frame pass for nothing (its answer is max_iter); sweeps
+    // stay in that regime for many batches in a row, so after such a batch the full run comes first.
+    auto all_flagged = [&](int iters_run, unsigned long long *all) -> int { // AND of the histories, first iters_run bits
         CLDPC_HIP(hipMemsetAsync(and_ws, 0xFF, sizeof(unsigned long long), st), BLDPC_EHIP);
         hipLaunchKernelGGL(k_hist_and, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, hist, F, and_ws);
-        unsigned long long all = 0; // bit it-1: every frame flagged after iteration it
-        CLDPC_HIP(hipMemcpyAsync(&all, and_ws, sizeof(all), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
+        CLDPC_HIP(hipMemcpyAsync(all, and_ws, sizeof(*all), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
         CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
-        if (run < 64) all &= ((1ull << run) - 1);
+        if (iters_run < 64) *all &= ((1ull << iters_run) - 1);
+        return BLDPC_OK;
+    };
+    int r;
+    int run = max_iter;
+    if (!q->ran_to_max) {
+        r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false);
+        if (r) return r;
+        int m = 0;
+        CLDPC_HIP(hipMemsetAsync(and_ws, 0, sizeof(unsigned long long), st), BLDPC_EHIP);
+        hipLaunchKernelGGL(k_iters_max, dim3(std::min((F + 255) / 256, 1024)), dim3(256), 0, st, iters_ws, F, (int *)and_ws);
+        CLDPC_HIP(hipMemcpyAsync(&m, and_ws, sizeof(int), hipMemcpyDeviceToHost, st), BLDPC_EHIP);
+        CLDPC_HIP(hipStreamSynchronize(st), BLDPC_EHIP);
+        if (m < 1 || m > max_iter) return fail(BLDPC_EHIP, "per-frame pass returned iteration count %d", m);
+        run = m;
+    }
+    for (;; run = std::min(max_iter, std::max(run + 4, 2 * run))) {
+        if ((r = qc_launch(q, y, F, run, length, D, app, hist, bits, st, ev0, ev1))) return r;
+        unsigned long long all = 0; // bit it-1: every frame flagged after iteration it
+        if ((r = all_flagged(run, &all))) return r;
         if (all) {
             const int stop = __builtin_ctzll(all) + 1;
             *itera = stop;
+            q->ran_to_max = (stop == max_iter);
             return stop < run ? qc_launch(q, y, F, stop, length, D, app, flag_hist, bits, st, ev0, ev1) : BLDPC_OK;
         }
         if (run == max_iter) {
             *itera = max_iter;
+            q->ran_to_max = 1;
             return BLDPC_OK;
         }
     }
