@@ -196,7 +196,17 @@ __global__ __launch_bounds__(256) void k_stat_errors(const int *D, const int *cw
     const int k0 = blockIdx.y * rows_per_slice, k1 = min(length, k0 + rows_per_slice);
     int e[4] = {0, 0, 0, 0};
     if (f + 3 < F && (F & 3) == 0) {
-        for (int k = k0; k < k1; k++) {
+        int k = k0;
+        if (!cw) { // all-zero codeword (the reference's PN_Message 0): eight rows in flight per lane
+            for (; k + 8 <= k1; k += 8) {
+                int4 d[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) d[i] = *reinterpret_cast<const int4 *>(D + (size_t)(k + i) * F + f);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { e[0] += d[i].x != 0; e[1] += d[i].y != 0; e[2] += d[i].z != 0; e[3] += d[i].w != 0; }
+            }
+        }
+        for (; k < k1; k++) {
             const int4 d = *reinterpret_cast<const int4 *>(D + (size_t)k * F + f);
             int4 c = make_int4(0, 0, 0, 0);
             if (cw) c = *reinterpret_cast<const int4 *>(cw + (size_t)k * F + f);
