@@ -250,6 +250,26 @@ def test_full_size_batch_properties(C, orc):
     assert r2["iteraTime"] == 1 and int(r2["D"][:N].sum()) == 0 and int(r2["D"][N].sum()) == 256
 
 
+@pytest.mark.parametrize("J,L,Z,snr,Fb,reps", [(32, 64, 64, 0.0, 16, 2048), (15, 30, 1280, 0.0, 4, 2048)])
+def test_full_size_batch_properties_configs_3_and_4(C, orc, J, L, Z, snr, Fb, reps):
+    """BASELINE configs 3 (32 768 frames) and 4 (8 192 frames) at full size, 50 iterations: an oracle-checked block tiled over
+    the batch decodes to the same columns in every tile, and the first tile equals the oracle bit for bit."""
+    N = L * Z
+    y = _channel(orc, N, Fb, snr).reshape(N, Fb)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    want = orc.bldpc_decode(ocode, y.reshape(-1), Fb, 50, early_exit=0)
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    yt = torch.from_numpy(y).cuda().repeat(1, reps).contiguous()
+    r = C.LDPC_Decoder_GPU(code, yt, max_iter=50, exit_mode=C.EXIT_FIXED)
+    torch.cuda.synchronize()
+    assert code.last_kernel.startswith("qc_lds")
+    D = r["D"].view(N + 1, reps, Fb)
+    assert bool((D == D[:, :1, :]).all())
+    assert np.array_equal(D[:, 0, :].contiguous().cpu().numpy().reshape(-1), want["D"])
+    del r, D, yt
+    torch.cuda.empty_cache()
+
+
 def test_statistic_matches_oracle(C, orc):
     J, L, Z, F = 4, 24, 96, 32
     y = _channel(orc, L * Z, F, 2.5)
