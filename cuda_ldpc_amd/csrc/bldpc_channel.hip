@@ -39,15 +39,19 @@ extern "C" int bldpc_awgn_channel_host(int seed[3], float sigma, float *out, con
 namespace {
 constexpr unsigned kA[3] = {249u, 251u, 252u}, kM[3] = {61967u, 63443u, 63599u}; // LDPC_Encoder.cu:48-50
 
+// a^k mod m for the three LCG moduli.  They are prime (61967, 63443, 63599), so a^(m-1) = 1 and the exponent reduces to
+// k mod (m-1) < 2^16; operands stay below 2^16, so every product fits 32 bits: at most 16 squarings of 32-bit arithmetic
+// per jump instead of up to 40 of 64-bit arithmetic.
 __host__ __device__ inline unsigned powmod(unsigned a, unsigned long long k, unsigned m)
 {
-    unsigned long long r = 1, b = a % m;
-    while (k) {
-        if (k & 1) r = (r * b) % m;
+    unsigned e = (unsigned)(k % (unsigned long long)(m - 1));
+    unsigned r = 1, b = a % m;
+    while (e) {
+        if (e & 1) r = (r * b) % m;
         b = (b * b) % m;
-        k >>= 1;
+        e >>= 1;
     }
-    return (unsigned)r;
+    return r;
 }
 
 // One thread per (frame f, run of kRun consecutive bits): jump the three LCGs to the first draw of the run

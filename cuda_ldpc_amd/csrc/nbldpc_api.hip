@@ -390,15 +390,17 @@ extern "C" int nbldpc_awgn_channel_host_qam(int seed[3], float sigma, const int 
 namespace {
 constexpr unsigned kNbA[3] = {249u, 251u, 252u}, kNbM[3] = {61967u, 63443u, 63599u}; // src/LDPC_Encoder.cpp:72-74
 
+// a^k mod m; the moduli are prime, so the exponent reduces mod (m - 1) and everything fits 32 bits (see bldpc_channel.hip)
 __host__ __device__ inline unsigned nb_powmod(unsigned a, unsigned long long k, unsigned m)
 {
-    unsigned long long r = 1, b = a % m;
-    while (k) {
-        if (k & 1) r = (r * b) % m;
+    unsigned e = (unsigned)(k % (unsigned long long)(m - 1));
+    unsigned r = 1, b = a % m;
+    while (e) {
+        if (e & 1) r = (r * b) % m;
         b = (b * b) % m;
-        k >>= 1;
+        e >>= 1;
     }
-    return (unsigned)r;
+    return r;
 }
 
 // One thread per (frame b, run of kNbRun consecutive bits): jump to draw 4*(b*N*m + i0), then step as RandomModule does.
