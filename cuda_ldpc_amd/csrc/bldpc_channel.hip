@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void k_awgn(unsigned s0, unsigned s1, unsigned
         for (int d = 0; d < 2; d++) {
 #pragma unroll
             for (int i = 0; i < 3; i++) s[i] = (s[i] * kA[i]) % kM[i];
-            float t = ((float)(int)s[0] / 61967.0f) + ((float)(int)s[1] / 63443.0f) + ((float)(int)s[2] / 63599.0f);
+            // x / m for an integer 0 <= x < m, m an odd prime below 2^16: the correctly rounded float quotient equals the double
+            // product x * (1/m) rounded to float (x/m is at least 2^-40 away, relatively, from every float rounding boundary;
+            // all 3 x 63 599 cases checked in tests/test_host_cpu.py) -- three conversions and a multiply instead of a division
+            float t = (float)((double)(int)s[0] * (1.0 / 61967.0)) + (float)((double)(int)s[1] * (1.0 / 63443.0)) + (float)((double)(int)s[2] * (1.0 / 63599.0));
             t -= (int)t;
             u[d] = t;
         }

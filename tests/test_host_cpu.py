@@ -210,3 +210,13 @@ def test_qam_constellation_and_channel_equal_the_restatement(nbm, orc):
         assert rx.shape == (96, 2) and np.array_equal(rx.view(np.uint32), want.view(np.uint32)) and np.array_equal(s1, s2)
     with pytest.raises(Exception):
         nbm.Get_CONSTELLATION(os.path.join(NB, "Constellation", "BPSK.txt"), 64)  # two records only
+
+
+def test_lcg_quotient_shortcut_exhaustive():
+    """The device channel generators form RandomModule's s / m (float division, LDPC_Encoder.cu:51-53) as the double product
+    s * (1/m) rounded to float: identical for every state of the three generators."""
+    for m in (61967, 63443, 63599):
+        x = np.arange(m, dtype=np.int32)
+        want = x.astype(np.float32) / np.float32(m)
+        got = (x.astype(np.float64) * np.float64(1.0 / m)).astype(np.float32)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
