@@ -37,6 +37,42 @@ struct CnAcc {
     __device__ __forceinline__ uint32_t key() const { return (f2u(m1) ^ f2u(m2)) ^ (sgn & 0x80000000u); }
 };
 
+// The two smallest magnitudes (with multiplicity) and the XOR of the sign bits of N values at once: what N calls of
+// CnAcc::add leave in (m1, m2, sgn), with 3-input instructions -- min3 / med3 of a triple, then
+// (m1, m2) <- (min(m1, lo), min3(max(m1, lo), m2, mid)): 5 instructions per 3 values instead of 6 (14 instead of 20 for the
+// ten edges of half a J4_L24_Z96 row; min / max / med3 all issue every 4.2 cycles per SIMD, profiles/r02_micro_rates.txt).
+// Selection only, no arithmetic: the same bits whatever the order.
+template <int N, int STRIDE> __device__ __forceinline__ void cn_two_smallest(const float *q, float &m1, float &m2, uint32_t &sgn)
+{
+    static_assert(N >= 2, "a check row half has at least two edges");
+    auto A = [&](int i) { return __builtin_fabsf(q[i * STRIDE]); };
+    int i = 0;
+    if (N >= 3) {
+        m1 = __builtin_fminf(__builtin_fminf(A(0), A(1)), A(2));
+        m2 = __builtin_amdgcn_fmed3f(A(0), A(1), A(2));
+        i = 3;
+    } else {
+        m1 = __builtin_fminf(A(0), A(1));
+        m2 = __builtin_fmaxf(A(0), A(1));
+        i = 2;
+    }
+#pragma unroll
+    for (; i + 3 <= N; i += 3) {
+        const float lo = __builtin_fminf(__builtin_fminf(A(i), A(i + 1)), A(i + 2));
+        const float mid = __builtin_amdgcn_fmed3f(A(i), A(i + 1), A(i + 2));
+        m2 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(m1, lo), m2), mid);
+        m1 = __builtin_fminf(m1, lo);
+    }
+#pragma unroll
+    for (; i < N; i++) {
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, A(i));
+        m1 = __builtin_fminf(m1, A(i));
+    }
+    sgn = 0u;
+#pragma unroll
+    for (int k = 0; k < N; k++) sgn ^= f2u(q[k * STRIDE]);
+}
+
 // R_i = Sign[25]*Sign[i] * (i == Index_minQ ? SubMinQ : MinQ)   (LDPC_Decoder.cu:298-312)
 //   clamp(q, -m2, +m2) = sign(q) * min(|q|, m2), which is sign(q)*m1 exactly for the
 //   edge(s) holding the minimum and sign(q)*m2 for every other edge; XOR with

@@ -36,6 +36,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "../../include/bldpc.h"
@@ -43,6 +44,15 @@
 #include "bldpc_qcc_kernel.hpp"
 #include "common.hpp"
 
+// Wave priorities of the half-row kernel's stages (s_setprio): the stages that only move messages through LDS (variable-node
+// phase, output stores) run above the arithmetic of the check-node phase.  Two workgroups share a CU and the hardware serves
+// the older one first: without this the younger workgroup crawls through its LDS-bound stages behind the older one's VALU work
+// (first 11 iterations at 8 000 cycles each against 3 000 later, profiles/r02_qc2_phase_probe.txt); with it 11.6 -> 12.3 M codewords/s.
+#ifndef QC_PRIO_VN
+#define QC_PRIO_VN 1
+#define QC_PRIO_CN 0
+#define QC_PRIO_WR 1
+#endif
 #ifndef QC_ABLATE
 #define QC_ABLATE 0 // experiments only: 1 no CN writes, 2 no CN S reads, 4 no barriers, 8 no CN R reads, 16 no VN reads, 32 no VN writes
 #endif
@@ -73,6 +83,10 @@ struct QcArgs {
     // iteration, and the workgroup leaves when all of its frames have stopped
     int per_frame;
     int *iters;                 // [F] iterations executed per frame (per_frame only)
+#ifdef QC_STAMPS
+    unsigned long long *stamps; // tools/qc_phase_probe.hip only: [nWG][QC_STAMPS] s_memtime stamps of wave 0
+    int stagger;                // tools only: cycles of s_sleep for workgroups with an odd TG_ID before the loop
+#endif
 };
 
 template <int NF> struct Msg;
@@ -407,18 +421,46 @@ template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int GJ_, int MINW_>
     static_assert(TPB <= 1024 && inf_slot < 65536, "geometry out of range");
 };
 
-__device__ __forceinline__ void swap32(float &lo_all, float &hi_all, float x)
+// v_permlane32_swap a, b: a <- [a.lo, b.lo], b <- [a.hi, b.hi] (lo = lanes 0-31, hi = lanes 32-63).
+__device__ __forceinline__ void swap32(uint32_t &a, uint32_t &b)
 {
-    // lo_all <- x of lanes 0-31 in both halves, hi_all <- x of lanes 32-63 in both halves
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    lo_all = __uint_as_float(r[0]);
-    hi_all = __uint_as_float(r[1]);
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
 }
 
+// LDS access of a frame pair by absolute LDS byte address (see lds_ld): one ds_read_b64 / ds_write_b64.
+typedef __attribute__((address_space(3))) v2f32 lds_v2;
+__device__ __forceinline__ v2f32 lds_ld2(int byte_off) { return *reinterpret_cast<const lds_v2 *>(static_cast<unsigned>(byte_off)); }
+__device__ __forceinline__ void lds_st2(int byte_off, v2f32 v) { *reinterpret_cast<lds_v2 *>(static_cast<unsigned>(byte_off)) = v; }
+// The same store at base + OFF with OFF in the instruction's offset field, kept out of the compiler's sight so that two of
+// them are not merged into one ds_write2_b64 (13.5 LDS cycles against 2 x 6.2).  The caller drains lgkmcnt before a barrier.
+template <int OFF> __device__ __forceinline__ void lds_st2_imm(int base, v2f32 v)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_write_b64 has a 16-bit offset");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(v), "n"(OFF) : "memory");
+}
+template <int... Is, typename Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// What bounds this kernel (profiles/r02_micro_rates.txt, measured on MI355X): per CU one ds_read_b64 costs 2.1 cycles, one
+// ds_write_b64 6.2, one ds_read2_b64 8.1 (twice two single reads); per SIMD add / sub / xor / mov issue every 2.5 cycles,
+// min / max / med3 / compares / packed f32 every 4.2, v_permlane32_swap every 8.3.  Hence:
+//   * a thread keeps its own previous outputs R_p in REGISTERS (it wrote them): the check-node phase reads only S from LDS
+//     (the aligned R reads of the earlier version were merged into ds_read2_b64 by the compiler: 40 LDS cycles per wave and
+//     iteration for what 10 registers hold);
+//   * the two halves of a row merge ONE-SIDED: three swaps hand lanes 0-31 both halves' (min1, min2, sign) of frame 0 and
+//     lanes 32-63 those of frame 1, every lane merges one frame, two more swaps hand both results to all lanes -- 5 swaps
+//     and one merge per lane instead of 6 swaps + 6 copies and two merges;
+//   * magnitudes merge as unsigned integers (same order as non-negative floats, +inf included; no canonicalising v_max).
 template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc2(QcArgs a)
 {
     constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, GJ = GM::GJ, ZB = GM::ZB, WCH = GM::WCH;
     constexpr int RPT = GM::RPT, CPT = GM::CPT, NCG = GM::NCG, MSG = GM::MSG;
+    static_assert(NF == 2, "the half-row kernel carries a frame pair per lane");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
@@ -436,6 +478,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     const int rbase = ((jq * WC + h * WCH) * Z + t) * MSG;   // + (rr*GJ*WC + i)*Z*MSG
     const int sbase = (GM::Sslot + cg * Z + t) * MSG;        // + cc*NCG*Z*MSG
     int saddr[RPT][WCH]; // byte addresses of the S values of this thread's edges
+    v2f32 Rr[RPT][WCH];  // this thread's previous outputs R_p (Memory_RQ = 0 at the start, LDPC_Decoder.cu:82)
     int e0v[RPT], wrv[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
@@ -456,11 +499,11 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             c = (c >= Z) ? c - Z : c;
             const int slot = (h * WCH + i < wrv[rr]) ? GM::Sslot + ed[i].col * Z + c : GM::inf_slot;
             saddr[rr][i] = slot * MSG;
-            const float zero[NF] = {};
-            lds_st<NF>(lds, rbase + (rr * GJ * WC + i) * Z * MSG, zero);
+            Rr[rr][i] = v2f32{0.0f, 0.0f};
+            lds_st2(rbase + (rr * GJ * WC + i) * Z * MSG, Rr[rr][i]);
         }
     }
-    float yreg[CPT][NF];
+    v2f32 yreg[CPT];
     int raddr[CPT][WV];
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
@@ -468,10 +511,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         QcVnEdge ed[WV];
 #pragma unroll
         for (int k = 0; k < WV; k++) ed[k] = a.vn_edges[l * WV + min(k, wcv[cc] - 1)];
-        {
-            typename Msg<NF>::T yv = *reinterpret_cast<const typename Msg<NF>::T *>(a.y + ((size_t)wg * (L * Z) + l * Z + t) * NF);
-            __builtin_memcpy(yreg[cc], &yv, sizeof(yv));
-        }
+        yreg[cc] = *reinterpret_cast<const v2f32 *>(a.y + ((size_t)wg * (L * Z) + l * Z + t) * NF);
 #pragma unroll
         for (int k = 0; k < WV; k++) {
             int r = t - ed[k].shift;
@@ -488,33 +528,42 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     unsigned long long hist = 0;
     unsigned done = 0; // per-frame exit, see k_qc
     constexpr unsigned ALL = (1u << NF) - 1u;
+#ifdef QC_STAMPS
+    int nst = 0;
+    auto stamp = [&](unsigned long long v) { if (tid == 0 && nst < QC_STAMPS) a.stamps[(size_t)wg * QC_STAMPS + nst++] = v; };
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    stamp(((unsigned long long)xcc << 32) | hwid);
+    stamp(__builtin_amdgcn_s_memtime());
+    if (a.stagger && ((hwid >> 16) & 1))
+        for (int i = 0; i < a.stagger; i += 64 * 16) __builtin_amdgcn_s_sleep(16);
+#endif
     __syncthreads();
+#ifdef QC_STAMPS
+    stamp(__builtin_amdgcn_s_memtime());
+#endif
 
+    // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.  0 + R_0 is a real addition:
+    // R_0 may be -0.0f (magnitude 0, sign -1) and (+0) + (-0) = +0 is what the reference computes.
     auto vn_phase = [&](bool (&bad)[NF]) {
-        float R[CPT][WV][NF];
+        v2f32 R[CPT][WV];
 #pragma unroll
         for (int cc = 0; cc < CPT; cc++)
 #pragma unroll
-            for (int k = 0; k < WV; k++) lds_ld<NF>(R[cc][k], lds, raddr[cc][k]);
+            for (int k = 0; k < WV; k++) R[cc][k] = lds_ld2(raddr[cc][k]);
+        static_for<CPT>([&](auto CC) {
+            constexpr int cc = decltype(CC)::value;
+            v2f32 S = v2f32{0.0f, 0.0f};
 #pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            float S[NF];
-#pragma unroll
-            for (int v = 0; v < NF; v++) S[v] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < WV; k++) {
-#pragma unroll
-                for (int v = 0; v < NF; v++) S[v] += R[cc][k][v];
-            }
-#pragma unroll
-            for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
-            lds_st<NF>(lds, sbase + cc * NCG * Z * MSG, S);
+            for (int k = 0; k < WV; k++) S = S + R[cc][k];
+            S = S + yreg[cc];
+            lds_st2_imm<cc * NCG * Z * MSG>(sbase, S);
             if (HIST) {
                 const bool in_len = ((cg + cc * NCG) * Z + t) < a.length;
-#pragma unroll
-                for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
+                bad[0] = bad[0] || (in_len && S.x < 0);
+                bad[1] = bad[1] || (in_len && S.y < 0);
             }
-        }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the stores above are invisible to the compiler's counters
     };
     auto flags_publish = [&](const bool (&bad)[NF], int it) { // two sets of flag words by iteration parity, see k_qc
 #pragma unroll
@@ -566,58 +615,71 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
+        __builtin_amdgcn_s_setprio(QC_PRIO_VN);
         vn_phase(bad);
         if (HIST) flags_publish(bad, it);
         __syncthreads();
+        __builtin_amdgcn_s_setprio(QC_PRIO_CN);
+#ifdef QC_STAMPS
+        stamp(__builtin_amdgcn_s_memtime());
+#endif
         if (HIST) {
             (void)flags_collect(it);
             if (a.per_frame && retire(it)) break;
         }
 
+        // CN phase (LDPC_Decoder.cu:279-314)
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
-            float Q[WCH][NF];
             CnAcc acc[NF];
+            {
+                v2f32 Sv[WCH];
+#pragma unroll
+                for (int i = 0; i < WCH; i++) Sv[i] = lds_ld2(saddr[rr][i]);
+#pragma unroll
+                for (int i = 0; i < WCH; i++) Rr[rr][i] = Sv[i] - Rr[rr][i]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
+            }
+#if QC_ACC_RUNNING
 #pragma unroll
             for (int v = 0; v < NF; v++) acc[v].init();
-            {
-                float Sv[WCH][NF], Rv[WCH][NF];
-#pragma unroll
-                for (int i = 0; i < WCH; i++) {
-                    lds_ld<NF>(Sv[i], lds, saddr[rr][i]);
-                    lds_ld<NF>(Rv[i], lds, rbase + (rr * GJ * WC + i) * Z * MSG);
-                }
-#pragma unroll
-                for (int i = 0; i < WCH; i++) {
-#pragma unroll
-                    for (int v = 0; v < NF; v++) {
-                        Q[i][v] = Sv[i][v] - Rv[i][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
-                        acc[v].add(Q[i][v]);
-                    }
-                }
-            }
-            // merge the two halves of the row: the two smallest of {m1,m2} U {m1',m2'}, XOR of the signs
-            uint32_t key[NF];
-            float m2[NF];
-#pragma unroll
-            for (int v = 0; v < NF; v++) {
-                float a1, b1, a2, b2, as, bs;
-                swap32(a1, b1, acc[v].m1);
-                swap32(a2, b2, acc[v].m2);
-                swap32(as, bs, __uint_as_float(acc[v].sgn));
-                const float m1 = __builtin_fminf(a1, b1);
-                m2[v] = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1, b1), a2), b2);
-                key[v] = (f2u(m1) ^ f2u(m2[v])) ^ ((f2u(as) ^ f2u(bs)) & 0x80000000u);
-            }
 #pragma unroll
             for (int i = 0; i < WCH; i++) {
-                float Rn[NF];
-#pragma unroll
-                for (int v = 0; v < NF; v++) Rn[v] = cn_out(Q[i][v], m2[v], key[v]);
-                lds_st<NF>(lds, rbase + (rr * GJ * WC + i) * Z * MSG, Rn);
+                acc[0].add(Rr[rr][i].x);
+                acc[1].add(Rr[rr][i].y);
             }
+#else
+            cn_two_smallest<WCH, 2>(reinterpret_cast<const float *>(&Rr[rr][0]), acc[0].m1, acc[0].m2, acc[0].sgn);
+            cn_two_smallest<WCH, 2>(reinterpret_cast<const float *>(&Rr[rr][0]) + 1, acc[1].m1, acc[1].m2, acc[1].sgn);
+#endif
+            // merge the two halves of the row: the two smallest of {m1,m2} U {m1',m2'}, XOR of the signs
+            uint32_t a1 = f2u(acc[0].m1), b1 = f2u(acc[1].m1), a2 = f2u(acc[0].m2), b2 = f2u(acc[1].m2), as = acc[0].sgn, bs = acc[1].sgn;
+            swap32(a1, b1); // lanes 0-31: (own, other half's) value of frame 0; lanes 32-63: (other half's, own) value of frame 1
+            swap32(a2, b2);
+            swap32(as, bs);
+            const uint32_t m1 = min(a1, b1);
+            uint32_t m2u = min(min(max(a1, b1), a2), b2);
+            uint32_t keyu = (m1 ^ m2u) ^ ((as ^ bs) & 0x80000000u);
+            uint32_t m2v = m2u, keyv = keyu;
+            swap32(m2u, m2v);   // m2u: frame 0 (computed by lanes 0-31), m2v: frame 1, in every lane
+            swap32(keyu, keyv);
+            const float m2f[NF] = {u2f(m2u), u2f(m2v)};
+            const uint32_t key[NF] = {keyu, keyv};
+            __builtin_amdgcn_s_setprio(QC_PRIO_WR);
+            static_for<RPT * WCH>([&](auto I) {
+                constexpr int r_ = decltype(I)::value / WCH, i = decltype(I)::value % WCH;
+                if (r_ != rr) return;
+                v2f32 Rn;
+                Rn.x = cn_out(Rr[rr][i].x, m2f[0], key[0]);
+                Rn.y = cn_out(Rr[rr][i].y, m2f[1], key[1]);
+                Rr[rr][i] = Rn;
+                lds_st2_imm<(r_ * GJ * WC + i) * Z * MSG>(rbase, Rn);
+            });
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef QC_STAMPS
+        stamp(__builtin_amdgcn_s_memtime());
+#endif
     }
 
     int flag = 0;
@@ -631,6 +693,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         __syncthreads();
         flag = flags_collect(a.max_iter);
     }
+#ifdef QC_STAMPS
+    stamp(__builtin_amdgcn_s_memtime());
+#endif
     if (tid < NF && f0 + tid < F) {
         const bool stopped = HIST && ((done >> tid) & 1u);
         a.D[(size_t)L * Z * F + f0 + tid] = stopped ? 1 : flag;
@@ -966,6 +1031,10 @@ inline const QcVariant *qc_variants(int *count)
 }
 
 constexpr size_t kLdsBytes = 160 * 1024;
+#ifdef QC_STAMPS
+static unsigned long long *g_qc_stamps = nullptr;
+static int g_qc_stagger = 0;
+#endif
 
 struct QcPlan {
     int J = 0, L = 0, Z = 0, nnz = 0, Wc = 0, Wv = 0;
@@ -1140,6 +1209,9 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     a.nWG = (F + q->frames_per_wg - 1) / q->frames_per_wg;
     a.max_iter = max_iter; a.length = length;
     a.cn_meta = q->d_cn_meta; a.vn_meta = q->d_vn_meta; a.J = q->J; a.L = q->L; a.WVS = q->WVS; a.lc = q->lc;
+#ifdef QC_STAMPS
+    a.stamps = g_qc_stamps; a.stagger = g_qc_stagger;
+#endif
     const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
     if (ev0) (void)hipEventRecord(ev0, st);
     hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);
