@@ -53,9 +53,6 @@
 #define QC_PRIO_CN 0
 #define QC_PRIO_WR 1
 #endif
-#ifndef QC_ABLATE
-#define QC_ABLATE 0 // experiments only: 1 no CN writes, 2 no CN S reads, 4 no barriers, 8 no CN R reads, 16 no VN reads, 32 no VN writes
-#endif
 
 namespace cldpc {
 
@@ -134,6 +131,25 @@ template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int G_, int MINW_> 
 // g is NOT wave-uniform (Z need not be a multiple of 64): nothing in the iteration loop depends on g
 // except per-lane base addresses, so no lane ever idles; the per-edge tables are gathered per lane,
 // once, in the prologue.
+// Store of one message (NF floats) at base + OFF with OFF in the instruction's offset field, as inline assembly: the compiler
+// merges two such stores into one ds_write2_b64 (13.5 LDS cycles against 2 x 6.2, profiles/r02_micro_rates.txt) when it sees
+// them.  Its lgkmcnt bookkeeping does not see these either: the caller drains the counter before a barrier.
+template <int NF, int OFF> __device__ __forceinline__ void lds_st_imm(int base, const float (&v)[NF])
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_write has a 16-bit offset");
+    if constexpr (NF == 2) {
+        v2f32 x = {v[0], v[1]};
+        asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(x), "n"(OFF) : "memory");
+    } else {
+        asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(base), "v"(v[0]), "n"(OFF) : "memory");
+    }
+}
+template <int... Is, typename Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc(QcArgs a)
 {
     constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, G = GM::G;
@@ -159,6 +175,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     unsigned saddr[RPT][(WC + 1) / 2];                 // S slots of the row's neighbours, packed 2 x 16 bit
     constexpr bool UNPACKED = RPT * WC <= 16;          // few enough to keep as byte addresses (saves 2 VALU per edge and iteration)
     int saddr_u[UNPACKED ? RPT : 1][UNPACKED ? WC : 1];
+    float Rr[RPT][WC][NF];                             // this thread's previous outputs R_p: it wrote them, it keeps them (see k_qc2)
     // All table gathers are issued unconditionally (index clamped into the row / column) and only then
     // consumed: predicated loads would be waited for one by one, ~0.4 us each under load.
     int e0v[RPT], wrv[RPT];
@@ -185,6 +202,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             if (UNPACKED) saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0] = slot * MSG;
             const float zero[NF] = {};
             lds_st<NF>(lds, rbase + (rr * G * WC + pp) * Z * MSG, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
+#pragma unroll
+            for (int v = 0; v < NF; v++) Rr[rr][pp][v] = 0.0f;
         }
     }
     float yreg[CPT][NF];
@@ -220,16 +239,15 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
     auto vn_phase = [&](bool (&bad)[NF]) {
         constexpr int CB = (CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1); // columns with reads in flight together
-#pragma unroll
-        for (int c0 = 0; c0 < CPT; c0 += CB) {
+        static_for<CPT / CB>([&](auto C0) {
+            constexpr int c0 = decltype(C0)::value * CB;
             float R[CB][WV][NF];
 #pragma unroll
             for (int ci = 0; ci < CB; ci++)
 #pragma unroll
                 for (int k = 0; k < WV; k++) lds_ld<NF>(R[ci][k], lds, raddr[c0 + ci][k]);
-#pragma unroll
-            for (int ci = 0; ci < CB; ci++) {
-                const int cc = c0 + ci;
+            static_for<CB>([&](auto CI) {
+                constexpr int ci = decltype(CI)::value, cc = c0 + ci;
                 float S[NF];
 #pragma unroll
                 for (int v = 0; v < NF; v++) S[v] = 0.0f;
@@ -240,15 +258,16 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 }
 #pragma unroll
                 for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
-                lds_st<NF>(lds, sbase + cc * G * Z * MSG, S);
+                lds_st_imm<NF, cc * G * Z * MSG>(sbase, S);
                 if (HIST) {
                     const bool in_len = ((g + cc * G) * Z + t) < a.length;
 #pragma unroll
                     for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
                 }
-            }
+            });
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the stores above are invisible to the compiler's counters
     };
 
     // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147).  Two sets of flag words, used by odd and even
@@ -270,6 +289,10 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     };
     // hard bits (and a-posteriori values) of the frames in `mask`, from the S values this thread has just published
     auto emit = [&](unsigned mask, bool (&bad)[NF]) {
+        // opaque copies: keeps the output addresses from being computed ahead of the iteration loop and held (or spilled) through it
+        unsigned *obits = a.bits;
+        float *oapp = a.app;
+        asm volatile("" : "+s"(obits), "+s"(oapp));
 #pragma unroll
         for (int cc = 0; cc < CPT; cc++) {
             const int n = (g + cc * G) * Z + t;
@@ -283,8 +306,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 // hard bits leave packed, one 32-bit word per half-wave: Z % 32 == 0 keeps the 32 lanes of a
                 // half-wave inside one thread group, i.e. on 32 consecutive variables n .. n+31, n % 32 == 0.
                 const unsigned long long m = __ballot(neg);
-                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
-                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
+                if ((tid & 31) == 0 && f0 + v < F) obits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (oapp && f0 + v < F) oapp[(size_t)n * F + f0 + v] = S[v];
             }
         }
     };
@@ -305,6 +328,40 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     };
 
     // ---- iterations 1 .. max_iter-1: VN, CN --------------------------------------------------
+    // One check row with exactly W edges (W <= WC; W < WC only where the row weight is wave-uniform, i.e. Z is whole waves:
+    // J32_L64_Z64 has rows of 5, 6 and 7 edges).  Rows lighter than W read the +inf slot in their padding positions.
+    auto cn_row = [&](auto RR, auto WW) {
+        constexpr int rr = decltype(RR)::value, W = decltype(WW)::value;
+        {
+            float Sv[W][NF];
+#pragma unroll
+            for (int pp = 0; pp < W; pp++) {
+                if (UNPACKED) lds_ld<NF>(Sv[pp], lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
+                else lds_ld<NF>(Sv[pp], lds, (int)((pp & 1) ? (saddr[rr][pp / 2] >> 16) : (saddr[rr][pp / 2] & 0xffffu)) * MSG);
+            }
+#pragma unroll
+            for (int pp = 0; pp < W; pp++)
+#pragma unroll
+                for (int v = 0; v < NF; v++) Rr[rr][pp][v] = Sv[pp][v] - Rr[rr][pp][v]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
+        }
+        float m2[NF];
+        uint32_t key[NF];
+#pragma unroll
+        for (int v = 0; v < NF; v++) {
+            CnAcc acc;
+            cn_two_smallest<W, NF>(&Rr[rr][0][v], acc.m1, acc.m2, acc.sgn);
+            m2[v] = acc.m2;
+            key[v] = acc.key();
+        }
+        __builtin_amdgcn_s_setprio(QC_PRIO_WR);
+        static_for<W>([&](auto PP) {
+            constexpr int pp = decltype(PP)::value;
+#pragma unroll
+            for (int v = 0; v < NF; v++) Rr[rr][pp][v] = cn_out(Rr[rr][pp][v], m2[v], key[v]);
+            lds_st_imm<NF, (rr * G * WC + pp) * Z * MSG>(rbase, Rr[rr][pp]);
+        });
+        __builtin_amdgcn_s_setprio(QC_PRIO_CN);
+    };
     for (int it = 1; it < a.max_iter; it++) {
         // keep the 16-bit-packed slot indices packed across iterations (unpacked they cost 2x the VGPRs)
 #pragma unroll
@@ -315,67 +372,31 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
+        __builtin_amdgcn_s_setprio(QC_PRIO_VN);
         vn_phase(bad);
         if (HIST) flags_publish(bad, it);
-        if (!(QC_ABLATE & 4)) __syncthreads();
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(QC_PRIO_CN);
         if (HIST) {
             (void)flags_collect(it);
             if (a.per_frame && retire(it)) break;
         }
 
         // CN phase (LDPC_Decoder.cu:279-314)
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) {
-            // CH: edges whose S and R reads are in flight together (bounds VGPR use)
-            constexpr int CH = (WC % 5 == 0) ? 5 : ((WC % 4 == 0) ? 4 : ((WC % 7 == 0) ? 7 : WC));
-            // When Z is a whole number of waves the row (hence its weight) is wave-uniform: the last two slots, the ones
-            // that may be padding, are skipped by a scalar branch instead of being computed on the +inf slot.
-            constexpr bool ROWU = (Z % 64 == 0);
-            const int wu = ROWU ? __builtin_amdgcn_readfirstlane(wrv[rr]) : WC;
-            auto slot_on = [&](int pp) -> bool { return !ROWU || pp < WC - 2 || pp < wu; };
-            float Q[WC][NF];
-            CnAcc acc[NF];
-#pragma unroll
-            for (int v = 0; v < NF; v++) acc[v].init();
-#pragma unroll
-            for (int p0 = 0; p0 < WC; p0 += CH) {
-                float Sv[CH][NF], Rv[CH][NF];
-#pragma unroll
-                for (int i = 0; i < CH; i++) {
-                    const int pp = p0 + i;
-                    const unsigned pk = saddr[rr][pp / 2];
-                    if (!slot_on(pp)) continue;
-                    if (UNPACKED) lds_ld<NF>(Sv[i], lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
-                    else if (!(QC_ABLATE & 2)) lds_ld<NF>(Sv[i], lds, (int)((pp & 1) ? (pk >> 16) : (pk & 0xffffu)) * MSG);
-                    else { for (int v = 0; v < NF; v++) Sv[i][v] = __uint_as_float(pk + pp + it); }
-                    if (!(QC_ABLATE & 8)) lds_ld<NF>(Rv[i], lds, rbase + (rr * G * WC + pp) * Z * MSG);
-                    else { for (int v = 0; v < NF; v++) Rv[i][v] = __uint_as_float(pk * 3 + pp); }
-                }
-#pragma unroll
-                for (int i = 0; i < CH; i++) {
-                    if (!slot_on(p0 + i)) continue;
-#pragma unroll
-                    for (int v = 0; v < NF; v++) {
-                        Q[p0 + i][v] = Sv[i][v] - Rv[i][v]; // Q = S - R  (LDPC_Decoder.cu:206-209)
-                        acc[v].add(Q[p0 + i][v]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        static_for<RPT>([&](auto RR) {
+            constexpr int rr = decltype(RR)::value;
+            constexpr bool ROWU = (Z % 64 == 0) && WC >= 4; // the row, hence its weight, is wave-uniform: a scalar branch picks the exact body
+            if constexpr (ROWU) {
+                const int wu = __builtin_amdgcn_readfirstlane(wrv[rr]);
+                if (wu <= WC - 2) cn_row(RR, std::integral_constant<int, WC - 2>{});
+                else if (wu == WC - 1) cn_row(RR, std::integral_constant<int, WC - 1>{});
+                else cn_row(RR, std::integral_constant<int, WC>{});
+            } else {
+                cn_row(RR, std::integral_constant<int, WC>{});
             }
-            uint32_t key[NF];
-#pragma unroll
-            for (int v = 0; v < NF; v++) key[v] = acc[v].key();
-#pragma unroll
-            for (int pp = 0; pp < WC; pp++) {
-                if (!slot_on(pp)) continue;
-                float Rn[NF];
-#pragma unroll
-                for (int v = 0; v < NF; v++) Rn[v] = cn_out(Q[pp][v], acc[v].m2, key[v]);
-                if (!(QC_ABLATE & 1)) lds_st<NF>(lds, rbase + (rr * G * WC + pp) * Z * MSG, Rn);
-                else if (Rn[0] == 1.2345f) lds_st<NF>(lds, rbase, Rn);
-            }
-        }
-        if (!(QC_ABLATE & 4)) __syncthreads();
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -----------
@@ -440,11 +461,6 @@ template <int OFF> __device__ __forceinline__ void lds_st2_imm(int base, v2f32 v
     static_assert(OFF >= 0 && OFF < 65536, "ds_write_b64 has a 16-bit offset");
     asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(v), "n"(OFF) : "memory");
 }
-template <int... Is, typename Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f)
-{
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // What bounds this kernel (profiles/r02_micro_rates.txt, measured on MI355X): per CU one ds_read_b64 costs 2.1 cycles, one
 // ds_write_b64 6.2, one ds_read2_b64 8.1 (twice two single reads); per SIMD add / sub / xor / mov issue every 2.5 cycles,
@@ -545,23 +561,28 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.  0 + R_0 is a real addition:
     // R_0 may be -0.0f (magnitude 0, sign -1) and (+0) + (-0) = +0 is what the reference computes.
     auto vn_phase = [&](bool (&bad)[NF]) {
-        v2f32 R[CPT][WV];
+        constexpr int CB = (CPT * WV <= 12) ? CPT : 1; // columns with reads in flight together
+        static_for<CPT / CB>([&](auto C0) {
+            constexpr int c0 = decltype(C0)::value * CB;
+            v2f32 R[CB][WV];
 #pragma unroll
-        for (int cc = 0; cc < CPT; cc++)
+            for (int ci = 0; ci < CB; ci++)
 #pragma unroll
-            for (int k = 0; k < WV; k++) R[cc][k] = lds_ld2(raddr[cc][k]);
-        static_for<CPT>([&](auto CC) {
-            constexpr int cc = decltype(CC)::value;
-            v2f32 S = v2f32{0.0f, 0.0f};
+                for (int k = 0; k < WV; k++) R[ci][k] = lds_ld2(raddr[c0 + ci][k]);
+            static_for<CB>([&](auto CI) {
+                constexpr int ci = decltype(CI)::value, cc = c0 + ci;
+                v2f32 S = v2f32{0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < WV; k++) S = S + R[cc][k];
-            S = S + yreg[cc];
-            lds_st2_imm<cc * NCG * Z * MSG>(sbase, S);
-            if (HIST) {
-                const bool in_len = ((cg + cc * NCG) * Z + t) < a.length;
-                bad[0] = bad[0] || (in_len && S.x < 0);
-                bad[1] = bad[1] || (in_len && S.y < 0);
-            }
+                for (int k = 0; k < WV; k++) S = S + R[ci][k];
+                S = S + yreg[cc];
+                lds_st2_imm<cc * NCG * Z * MSG>(sbase, S);
+                if (HIST) {
+                    const bool in_len = ((cg + cc * NCG) * Z + t) < a.length;
+                    bad[0] = bad[0] || (in_len && S.x < 0);
+                    bad[1] = bad[1] || (in_len && S.y < 0);
+                }
+            });
+            if (CB < CPT) __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the stores above are invisible to the compiler's counters
     };
@@ -580,6 +601,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         return flag;
     };
     auto emit = [&](unsigned mask, bool (&bad)[NF]) {
+        unsigned *obits = a.bits; // opaque copies, see k_qc
+        float *oapp = a.app;
+        asm volatile("" : "+s"(obits), "+s"(oapp));
 #pragma unroll
         for (int cc = 0; cc < CPT; cc++) {
             const int n = (cg + cc * NCG) * Z + t;
@@ -591,8 +615,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
                 const bool neg = S[v] < 0;
                 if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
                 const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave, see k_qc
-                if ((tid & 31) == 0 && f0 + v < F) a.bits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
-                if (a.app && f0 + v < F) a.app[(size_t)n * F + f0 + v] = S[v];
+                if ((tid & 31) == 0 && f0 + v < F) obits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
+                if (oapp && f0 + v < F) oapp[(size_t)n * F + f0 + v] = S[v];
             }
         }
     };
@@ -632,12 +656,17 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
             CnAcc acc[NF];
-            {
-                v2f32 Sv[WCH];
+            {   // in two batches: every load in flight holds a register pair, and 6 waves per SIMD leave 80 registers per lane
+                constexpr int CHK = (WCH > 6) ? (WCH + 1) / 2 : WCH;
 #pragma unroll
-                for (int i = 0; i < WCH; i++) Sv[i] = lds_ld2(saddr[rr][i]);
+                for (int c0 = 0; c0 < WCH; c0 += CHK) {
+                    v2f32 Sv[CHK];
 #pragma unroll
-                for (int i = 0; i < WCH; i++) Rr[rr][i] = Sv[i] - Rr[rr][i]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
+                    for (int i = 0; i < CHK && c0 + i < WCH; i++) Sv[i] = lds_ld2(saddr[rr][c0 + i]);
+#pragma unroll
+                    for (int i = 0; i < CHK && c0 + i < WCH; i++) Rr[rr][c0 + i] = Sv[i] - Rr[rr][c0 + i]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
+                    if (c0 + CHK < WCH) __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #if QC_ACC_RUNNING
 #pragma unroll
