@@ -87,10 +87,12 @@ def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
 
 
 def pmc_onchip(kernel_name, kern_ms):
-    """On-chip utilisation of the dominant kernel from the committed SQ counter pass (profiles/*_pmc.json "sq"):
-    the fused kernels are bound by the VALU issue rate and the LDS pipe, not by HBM, so this is the roofline that
-    says how far they are from their own ceiling.  VALU: wave-instructions * 2 cycles / (1024 SIMDs); LDS: array-active
-    cycles / (256 CUs); both over the kernel's cycles at the clock the counters saw (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    """On-chip picture of the dominant kernel, looked up in the committed SQ counter passes (profiles/*_pmc.json "sq") --
+    NOT measured in this run; "source" names the file.  The fused kernels are bound by VALU issue and the LDS pipe, not by
+    HBM.  Reported: the wave-cycle split the guide defines (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, with
+    WAIT_INST_LDS a sub-bucket of WAIT_INST_ANY), instruction counts per SIMD-cycle, and the pipe loads those counts imply at
+    the issue rates measured in profiles/r02_micro_rates.txt (full-rate VALU 2.5 cycles, half-rate 4.2, ds_read_b64 2.1,
+    ds_write_b64 6.2) -- SQ_ACTIVE_INST_VALU is one quad-cycle per instruction on gfx950 and says nothing about pipe time."""
     import glob
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
@@ -101,29 +103,32 @@ def pmc_onchip(kernel_name, kern_ms):
         if j.get("kernel") != kernel_name or "SQ_INSTS_VALU" not in sq:
             continue
         cycles = j["avg_ms"] * 1e-3 * 2.3e9 if not sq.get("GRBM_GUI_ACTIVE") else sq["GRBM_GUI_ACTIVE"] / 8.0
-        # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md, PMC units) of VALU execution summed over the 1024 SIMDs;
-        # a plain 2-operand instruction costs ~2.5 SIMD-cycles, 3-operand / DPP / 64-bit ones ~4.4 (tools/valu_rate.hip)
-        busy = sq.get("SQ_ACTIVE_INST_VALU")
-        return {"valu_busy": (busy * 4.0 / 1024.0 / cycles) if busy else None,
-                "valu_instructions_per_simd_cycle": sq["SQ_INSTS_VALU"] / 1024.0 / cycles, "lds_array_util": sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles,
-                "lds_bank_conflict_cycles": sq.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.basename(p),
-                "note": "profiled pass; kernel cycles from %s" % ("GRBM_GUI_ACTIVE/8" if sq.get("GRBM_GUI_ACTIVE") else "avg_ms * 2.3 GHz")}
+        wc = sq.get("SQ_WAVE_CYCLES")
+        split = None
+        if wc and sq.get("SQ_WAIT_ANY") is not None:
+            split = {k: sq[c] / wc for k, c in (("wait_any", "SQ_WAIT_ANY"), ("wait_inst_any", "SQ_WAIT_INST_ANY"),
+                                                ("active_inst_any", "SQ_ACTIVE_INST_ANY"), ("wait_inst_lds", "SQ_WAIT_INST_LDS")) if sq.get(c) is not None}
+        return {"wave_cycle_split": split, "valu_instructions_per_simd_cycle": sq["SQ_INSTS_VALU"] / 1024.0 / cycles,
+                "lds_instructions_per_cu_cycle": (sq["SQ_INSTS_LDS"] / 256.0 / cycles) if sq.get("SQ_INSTS_LDS") else None,
+                "lds_array_util": sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles, "lds_bank_conflict_cycles": sq.get("SQ_LDS_BANK_CONFLICT"),
+                "source": "committed profile " + os.path.basename(p),
+                "note": "profiled pass of an earlier run of this command, not this run; kernel cycles from %s" % ("GRBM_GUI_ACTIVE/8" if sq.get("GRBM_GUI_ACTIVE") else "avg_ms * 2.3 GHz")}
     return None
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
-    written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command); None when
-    no summary exists for this kernel."""
+    """(HBM bytes per launch of the dominant kernel, file it came from): a look-up into the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json, written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE runs of this same
+    command), not a measurement of this run; (None, None) when no summary exists for this kernel."""
     import glob
-    best = None
+    best = (None, None)
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             j = json.load(open(p))
         except Exception:
             continue
         if j.get("kernel") == kernel_name and j.get("hbm_bytes_per_launch"):
-            best = j["hbm_bytes_per_launch"]
+            best = (j["hbm_bytes_per_launch"], "committed profile " + os.path.basename(p))
     return best
 
 
@@ -219,7 +224,7 @@ def run_nb(args, rank, world, dev, dist):
         "config": {"workload": "myNBLDPC BDS N576_K288 %s batch=%d codewords/GPU Eb/N0=%.1fdB" % ("GF(64) EMS(Nm=2,Nc=2)" if method == 0 else mname, frames, snr),
                    "kernel": "%s one frame per workgroup" % kname, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(kname), "kernel": kname, "kernel_ms": kern_ms,
+                     "traffic": pmc_traffic(kname)[0], "traffic_source": pmc_traffic(kname)[1], "kernel": kname, "kernel_ms": kern_ms,
                      "onchip": pmc_onchip(kname, kern_ms),
                      "algorithmic_bytes_per_launch": alg_bytes},
         "stats": {"frames": n_all, "error_frames": c[0], "symbol_errors": c[1], "FER": c[0] / n_all, "SER": c[1] / n_all / code.N,
@@ -344,7 +349,9 @@ def main():
             "config": {"workload": "%s rate-%.3f batch=%d codewords/GPU %d iters Es/N0=%.1fdB" % (args.workload, code.K / N, frames, iters, snr),
                        "kernel": code.last_kernel, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(code.last_kernel), "kernel": code.last_kernel, "kernel_ms": kern_ms, "decode_call_ms": call_ms,
+                         "traffic": pmc_traffic(code.last_kernel)[0], "traffic_source": pmc_traffic(code.last_kernel)[1],
+                         "kernel": code.last_kernel, "kernel_ms": kern_ms, "decode_call_ms": call_ms,
+                         "achieved_decode_call": alg_bytes / (call_ms * 1e-3) / 1e9,  # regroup + decode + unpack: the kernels that move the algorithmic bytes
                          "algorithmic_bytes_per_launch": alg_bytes, "model": model, "onchip": pmc_onchip(code.last_kernel, kern_ms)},
             "stats": {"frames": frames * world * args.steps, "error_frames": c[0], "error_bits": c[1],
                       "FER": c[0] / (frames * world * args.steps), "BER": c[1] / (frames * world * args.steps) / code.K},

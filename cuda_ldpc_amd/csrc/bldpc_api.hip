@@ -306,11 +306,18 @@ static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int l
         return fail(BLDPC_EINVAL, "unknown exit_mode %d", exit_mode);
     hipStream_t st = (hipStream_t)stream;
     const bool qc_ok = c->has_qc && c->qc.frames_per_wg > 0;
-    if (kernel == BLDPC_KERNEL_AUTO) kernel = qc_ok ? BLDPC_KERNEL_QC_LDS : BLDPC_KERNEL_TABLE;
+    // The fused kernels keep a frame's flag history in one 64-bit word: the reference's batch-global rule (which is found
+    // from the histories) and a requested flag_hist need max_iter <= 64 there.  The reference takes any maxIT, and so do the
+    // table kernels: AUTO goes to them; only an explicit QC_LDS request is refused.
+    const bool needs_hist = exit_mode == BLDPC_EXIT_BATCH_GLOBAL || flag_hist != nullptr;
+    if (kernel == BLDPC_KERNEL_AUTO) kernel = (qc_ok && !(needs_hist && max_iter > 64)) ? BLDPC_KERNEL_QC_LDS : BLDPC_KERNEL_TABLE;
     if (kernel == BLDPC_KERNEL_QC_LDS) {
         if (!qc_ok)
             return fail(BLDPC_EUNSUPPORTED, "QC_LDS kernel unavailable for this code (%s)",
                         c->has_qc ? "message state exceeds LDS" : "built from an address table");
+        if (needs_hist && max_iter > 64)
+            return fail(BLDPC_EUNSUPPORTED, "QC_LDS with a flag history (BATCH_GLOBAL exit or flag_hist) supports max_iter <= 64 (got %d); "
+                        "BLDPC_KERNEL_AUTO or BLDPC_KERNEL_TABLE take any max_iter", max_iter);
         CLDPC_HIP(c->bad.reserve((size_t)F * sizeof(unsigned long long)), BLDPC_ENOMEM);
         CLDPC_HIP(c->cnt.reserve(64), BLDPC_ENOMEM);
         CLDPC_HIP(c->bits.reserve((size_t)F * (c->N / 32) * sizeof(unsigned)), BLDPC_ENOMEM);

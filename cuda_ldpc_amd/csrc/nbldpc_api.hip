@@ -231,7 +231,9 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     }
     if (!r) {
         hipError_t e = hipSuccess;
-        e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // the attribute belongs to the kernel, not to this code: set it to the CU's whole LDS once and for all, so that
+        // creating a second code with a smaller state never lowers the cap under the first one
+        e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     if (r) { nbldpc_code_destroy(c); return r; }

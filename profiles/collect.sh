@@ -14,5 +14,7 @@ rocprofv3 --pmc FETCH_SIZE -d ${out}_fetch -o run -- python bench.py "$@" --no-c
 rocprofv3 --pmc WRITE_SIZE -d ${out}_write -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d ${out}_sq -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_sq.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY -d ${out}_sq2 -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_sq2.log 2>&1
-python profiles/summarize.py $tag $name ${out}_trace ${out}_fetch ${out}_write ${out}_sq,${out}_sq2 "$match"
+# the wave-cycle split of MI355X_MICROARCH.md (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES)
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES -d ${out}_sq3 -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_sq3.log 2>&1
+python profiles/summarize.py $tag $name ${out}_trace ${out}_fetch ${out}_write ${out}_sq,${out}_sq2,${out}_sq3 "$match"
 cp ${out}_bench.json profiles/${tag}_${name}_bench.json

@@ -2,7 +2,10 @@
 // (myNBLDPC/include/LDPC_Decoder.h:13,23,25) as thin wrappers over include/nbldpc.h.  Kept: return value, iter_number,
 // DecodeOutput, the state left in VN[].LLR and CN[].L_c2v (q-1 entries for EMS, q for the trellis decoders), one frame
 // per call, callable from several host threads (the code object is shared and read-only, buffers are per thread).
-// Not kept: the per-call mallocs of the GPU twin (Decode_GPU.cu:144-167).
+// Not kept: the per-call mallocs of the GPU twin (Decode_GPU.cu:144-167); VN[].sort_L_v2c / sort_Entr_v2c, the scratch of the
+// CPU decoder's sort (LDPC_Decoder.cpp:247-266) -- no caller of the reference reads them after the call (decode_once_cpu / _gpu
+// read DecodeOutput and iter_number, Simulation.cpp:56-83,130-160) and the reference's own GPU twin leaves them at their
+// initial value, the channel vector (Decode_GPU.cu:170-177): here they are left untouched.
 #include "nbldpc_ref_shim.hpp"
 
 #include <hip/hip_runtime.h>
@@ -66,7 +69,7 @@ struct Buffers {
 // method: 0 EMS, 1 TMM, 3 layered TMM (define.h:37)
 int decode_one(int method, const LDPCCode *H, VN *V, CN *C, int Nm, int Nc, int *DecodeOutput, int &iter_number)
 {
-    if (!g_code) build_code(H, V, C);
+    build_code(H, V, C); // takes the mutex and returns at once when the code exists: THREAD_NUM host threads call in here (Simulation.cpp:175-185)
     const Cfg &c = g_cfg;
     const int N = H->Variablenode_num, M = H->Checknode_num, q = c.q, nv = (method == 0) ? q - 1 : q;
     thread_local Buffers b;
