@@ -378,6 +378,74 @@ def test_reference_signature_shim_cpp_harness(C, tmp_path):
     assert "hash=90c5df9b iteraTime=50" in out, out
 
 
+def _build_cpp(root, so_path, tmp_path, name, sources):
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / name)
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "shim")]
+                          + [os.path.join(root, s) for s in sources] + ["-o", exe, "-L", os.path.dirname(so_path), "-lcuda_ldpc_amd",
+                                                                         "-Wl,-rpath," + os.path.dirname(so_path)])
+    return exe
+
+
+@pytest.mark.parametrize("as_written", [0, 1])
+def test_reference_main_style_sweep_cpp_harness(C, orc, tmp_path, as_written):
+    """A sweep written like the reference's main() (main.cu:114-160) drives Get_H, Transform_H, Simulation_GPU, Statistic and
+    LDPC_Decoder_GPU with the reference's signatures and structs (shim/ldpc_ref_shim.hpp).  Every SNR point's counters equal
+    a CPU replay of the same loop through the oracle; with the intended circulant table the shim reaches the fused kernel
+    (it reads the shifts back from the table), with the table as written the table kernels."""
+    import subprocess
+    from cuda_ldpc_amd._lib import SO_PATH
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    exe = _build_cpp(root, SO_PATH, tmp_path, "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+    J, L, Z, F, maxIT = 4, 24, 96, 256, 50
+    out = subprocess.check_output([exe, _path(J, L, Z), str(J), str(L), str(Z), str(F), str(maxIT), str(as_written), "3.0", "3.5", "0.2",
+                                   "3", "512"]).decode()
+    pts = [ln.split() for ln in out.splitlines() if ln.startswith("POINT")]
+    assert len(pts) == 3 and "task finish" in out  # 3.0, 3.2 (3.20000005), 3.4 (3.4000001): a float advanced by a double step
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z, literal=bool(as_written))
+    snr = np.float32(3.0)
+    for p in pts:
+        assert abs(float(p[1]) - float(snr)) < 1e-6
+        oseed = np.array([173, 173, 173], np.int32)
+        cnt = np.zeros(5, np.int64)
+        frames = 0
+        while True:
+            frames += F
+            y = orc.bldpc_awgn(oseed, orc.bldpc_sigma(float(snr)), ocode.N, F)
+            r = orc.bldpc_decode(ocode, y, F, maxIT, early_exit=1)
+            if orc.bldpc_statistic(cnt, frames, r["D"], ocode.N, F, ocode.K, r["it"], least_err=3, least_frames=512):
+                break
+        assert [int(x) for x in p[2:8]] == [frames] + cnt.tolist(), (p, frames, cnt)
+        assert p[8].startswith("kernel=table" if as_written else "kernel=qc_lds"), p[8]
+        snr = np.float32(np.float64(snr) + 0.2)
+    rows = [ln for ln in out.splitlines() if ln.startswith(" 3.")]
+    assert len(rows) >= 3  # the reference's result rows (Simulation.cu:272)
+
+
+def test_max_iter_above_64_falls_back_to_the_table_kernels(C, orc):
+    """The reference takes any maxIT (define.cuh:35).  The fused kernels keep 64 iterations of flag history, so
+    KERNEL_AUTO sends a batch-global decode with max_iter > 64 to the table kernels instead of refusing it; an explicit
+    QC_LDS request is still refused."""
+    J, L, Z, F = 4, 24, 96, 16
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    ocode = orc.BinaryCode(_path(J, L, Z), J, L, Z)
+    y = _channel(orc, code.N, F, 2.0)  # a frame that never passes: the batch runs to max_iter
+    want = orc.bldpc_decode(ocode, y, F, 70, early_exit=1, want_app=True)
+    assert want["it"] == 70
+    got = _decode(C, code, y, F, max_iter=70, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
+    assert code.last_kernel.startswith("table")
+    _assert_same(got, want, code.N, F)
+    with pytest.raises(Exception):
+        _decode(C, code, y, F, max_iter=70, exit_mode=C.EXIT_BATCH_GLOBAL, kernel=C.KERNEL_QC_LDS)
+    got = _decode(C, code, y, F, max_iter=70, exit_mode=C.EXIT_FIXED, want_app=True)  # fixed iterations: no history needed
+    assert code.last_kernel.startswith("qc_lds")
+    _assert_same(got, orc.bldpc_decode(ocode, y, F, 70, early_exit=0, want_app=True), code.N, F)
+
+
 def test_bench_contract_line(C):
     """bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`."""
     import json

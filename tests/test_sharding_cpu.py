@@ -107,3 +107,46 @@ def test_snr_grid_matches_reference_float_accumulation():
     assert np.float32(g[1]) == np.float32(0.200000003) and np.float32(g[3]) == np.float32(0.600000024)
     assert abs(g[-1] - 12.9999924) < 1e-6
     assert snr_grid(0, 5, 0.5) == [0.5 * i for i in range(11)]
+
+
+def test_fixed_and_per_frame_counters_do_not_depend_on_world_size(orc):
+    """Simulation_GPU shards a batch by frames and evaluates the exit rule per shard (cuda_ldpc_amd/simulation.py).  With
+    EXIT_FIXED (every frame runs maxIT iterations) and EXIT_PER_FRAME (every frame stops on its own flag) a frame's result
+    does not depend on its batch, so the summed counters are the same for every world size.  The reference's batch-global
+    rule (LDPC_Decoder.cu:150-153: everybody iterates until the slowest frame of the BATCH passes) is evaluated per shard,
+    as SURVEY 8e prescribes: iteraTime, Total_Iteration and even D of a shard may then differ from the unsharded batch --
+    that mode is world-size DEPENDENT by construction, and the reference itself changes its output with Num_Frames_OneTime."""
+    from cuda_ldpc_amd import sharding
+    J, L, Z, F, snr, maxIT = 4, 24, 96, 12, 3.4, 50
+    ocode = orc.BinaryCode(os.path.join(BL, "J4_L24_Z96_BlockH.txt"), J, L, Z)
+    seed = np.array([173, 173, 173], np.int32)
+    y = orc.bldpc_awgn(seed, orc.bldpc_sigma(snr), ocode.N, F).reshape(ocode.N, F)
+
+    def counters(world, mode):
+        tot = np.zeros(5, np.int64)
+        iters = []
+        for rank in range(world):
+            first, count = sharding.shard_frames(F, world, rank)
+            if not count:
+                continue
+            if mode == "per_frame":  # each frame alone under the reference rule = Num_Frames_OneTime 1
+                for f in range(first, first + count):
+                    r = orc.bldpc_decode(ocode, np.ascontiguousarray(y[:, f]), 1, maxIT, early_exit=1)
+                    orc.bldpc_statistic(tot, 0, r["D"], ocode.N, 1, ocode.K, r["it"])
+                    iters.append(r["it"])
+            else:
+                ys = np.ascontiguousarray(y[:, first:first + count]).reshape(-1)
+                r = orc.bldpc_decode(ocode, ys, count, maxIT, early_exit=1 if mode == "batch_global" else 0)
+                orc.bldpc_statistic(tot, 0, r["D"], ocode.N, count, ocode.K, r["it"])
+                iters.append(r["it"])
+        return tot.tolist(), iters
+
+    for mode in ("fixed", "per_frame"):
+        base, _ = counters(1, mode)
+        for world in (2, 3, 5):
+            assert counters(world, mode)[0] == base, (mode, world)
+    # batch-global: the shards stop at different iterations, Total_Iteration follows
+    one, it1 = counters(1, "batch_global")
+    two, it2 = counters(2, "batch_global")
+    assert len(set(it2)) == 2 and max(it2) == it1[0] and two[2] < one[2]
+    assert one[0] == two[0] and one[1] == two[1]  # error frames / bits agree at this point (every frame converges)
