@@ -446,6 +446,35 @@ def test_max_iter_above_64_falls_back_to_the_table_kernels(C, orc):
     _assert_same(got, orc.bldpc_decode(ocode, y, F, 70, early_exit=0, want_app=True), code.N, F)
 
 
+def test_bench_two_ranks_share_one_gpu_over_gloo(C):
+    """The N > 1 path of bench.py as the driver launches it (python -m torch.distributed.run, one process per rank), rehearsed on
+    this box's single GPU: BENCH_SINGLE_DEVICE=1 puts both ranks on cuda:0, BENCH_DIST_BACKEND=gloo carries the one collective of
+    the path (the all-reduce of the 5 error counters).  Weak scaling: every rank decodes its own 2048 frames of the same tiled
+    block, so the job-wide counters are exactly twice the single-rank ones."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--frames", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.check_output([sys.executable, os.path.join(root, "bench.py")] + common, stderr=subprocess.DEVNULL).decode()
+    j1 = json.loads([ln for ln in one.splitlines() if ln.startswith("{")][0])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    two = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                                  stderr=subprocess.DEVNULL, env=env, timeout=600).decode()
+    lines = [ln for ln in two.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints, once
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0
+    for k in ("frames", "error_frames", "error_bits"):
+        assert j2["stats"][k] == 2 * j1["stats"][k], (k, j1["stats"], j2["stats"])
+    assert j1["stats"]["error_frames"] > 0
+
+
 def test_bench_contract_line(C):
     """bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`."""
     import json
