@@ -138,6 +138,79 @@ template <int K, int W> __device__ __forceinline__ void nb_bitonic_sort(uint32_t
     nb_bitonic_merge<K, K / 2, W>(hi, lo);
 }
 
+// The same network on ONE 32-bit key per lane: the order-preserving image of the value with its low 6 bits replaced by
+// 63 - index.  Half the instructions of the 64-bit step (one partner fetch, one v_cmp, one select) -- and exact only when no two
+// values of the vector differ in nothing but those 6 bits, so the caller VERIFIES the resulting permutation against the full
+// (value, index) order and repeats the vector on the 64-bit network when a neighbouring pair is out of order (the keys are
+// pairwise distinct, so the permutation whose neighbours are all in order is the one the stable sort produces).
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32(uint32_t &k)
+{
+    constexpr unsigned long long KM = nb_keepmax_mask(K, J);
+    uint32_t pk;
+    if constexpr (J == 1 || J == 2 || J == 8) {
+        constexpr int CTRL = (J == 1) ? 0xB1 : (J == 2) ? 0x4E : 0x128; // quad_perm [1,0,3,2], [2,3,0,1], row_ror:8
+        pk = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, 0xf, 0xf, false);
+    } else if constexpr (J < 32) {
+        pk = (uint32_t)__builtin_amdgcn_ds_swizzle((int)k, (J << 10) | 0x1f);
+    } else {
+        pk = (uint32_t)__shfl_xor((int)k, 32, 64);
+    }
+    const bool take = __builtin_amdgcn_inverse_ballot_w64(~(__builtin_amdgcn_ballot_w64(pk > k) ^ KM));
+    k = take ? pk : k;
+}
+// Four sorts through one DPP step, written out: the compiler's version spends 7 issue slots per sort (a copy for the DPP's tied
+// operand, s_nop hazard pads, everything through VCC); here the four sorts interleave so that every hazard distance is met by
+// useful instructions and each compare keeps its own SGPR pair: 4 x (v_mov_b32_dpp, v_cmp, s_xor, v_cndmask).
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32x4_dpp(uint32_t (&k)[4])
+{
+    static_assert(J == 1 || J == 2 || J == 8, "partners inside a row of 16");
+    constexpr unsigned long long NKM = ~nb_keepmax_mask(K, J); // take = (pk > k) XNOR keepmax = (pk > k) XOR ~keepmax
+    const unsigned long long nkm = NKM;
+    uint32_t p0, p1, p2, p3;
+    unsigned long long m0, m1, m2, m3;
+#define NB_DPP_STEP(CTRL)                                                                                     \
+    asm volatile("s_nop 1\n\t" /* a DPP source written by the VALU instruction just before needs 2 wait states */  \
+                 "v_mov_b32_dpp %4, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_mov_b32_dpp %5, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_mov_b32_dpp %6, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_mov_b32_dpp %7, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cmp_gt_u32_e64 %8, %4, %0\n\t"                                                              \
+                 "v_cmp_gt_u32_e64 %9, %5, %1\n\t"                                                              \
+                 "v_cmp_gt_u32_e64 %10, %6, %2\n\t"                                                             \
+                 "v_cmp_gt_u32_e64 %11, %7, %3\n\t"                                                             \
+                 "s_xor_b64 %8, %8, %12\n\t"                                                                    \
+                 "s_xor_b64 %9, %9, %12\n\t"                                                                    \
+                 "s_xor_b64 %10, %10, %12\n\t"                                                                  \
+                 "s_xor_b64 %11, %11, %12\n\t"                                                                  \
+                 "v_cndmask_b32_e64 %0, %0, %4, %8\n\t"                                                         \
+                 "v_cndmask_b32_e64 %1, %1, %5, %9\n\t"                                                         \
+                 "v_cndmask_b32_e64 %2, %2, %6, %10\n\t"                                                        \
+                 "v_cndmask_b32_e64 %3, %3, %7, %11"                                                             \
+                 : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&s"(m0), "=&s"(m1), \
+                   "=&s"(m2), "=&s"(m3)                                                                         \
+                 : "s"(nkm)                                                                                     \
+                 : "scc")
+    if constexpr (J == 1) { NB_DPP_STEP("quad_perm:[1,0,3,2]"); }
+    else if constexpr (J == 2) { NB_DPP_STEP("quad_perm:[2,3,0,1]"); }
+    else { NB_DPP_STEP("row_ror:8"); }
+#undef NB_DPP_STEP
+}
+template <int K, int J, int W> __device__ __forceinline__ void nb_bitonic_merge32(uint32_t (&k)[W])
+{
+    if constexpr (W == 4 && (J == 1 || J == 2 || J == 8)) {
+        nb_bitonic_step32x4_dpp<K, J>(k);
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; i++) nb_bitonic_step32<K, J>(k[i]);
+    }
+    if constexpr (J > 1) nb_bitonic_merge32<K, J / 2, W>(k);
+}
+template <int K, int W> __device__ __forceinline__ void nb_bitonic_sort32(uint32_t (&k)[W])
+{
+    if constexpr (K > 2) nb_bitonic_sort32<K / 2, W>(k);
+    nb_bitonic_merge32<K, K / 2, W>(k);
+}
+
 template <int NACT> struct NbCn {
     int pb[NACT];                   // float index of each active neighbour's sorted pairs
     float v0[NACT], v1[NACT];       // its two largest values   (sort_L_v2c[..][0..1])
@@ -438,7 +511,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         // ---- B: stable descending sort of every v2c vector (:17-36, :253-269) -----------------
         constexpr int SW = 4; // sorts in flight per wave
         for (int e0 = wave * SW; e0 < NE; e0 += nwaves * SW) {
-            uint32_t khi[SW], klo[SW];
+            uint32_t khi[SW], k32[SW];
             bool live[SW];
 #pragma unroll
             for (int i = 0; i < SW; i++) {
@@ -448,17 +521,41 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
                 // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
                 const uint32_t b = __float_as_uint(val + 0.0f);
                 khi[i] = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
-                klo[i] = 63u - (unsigned)lane; // stable descending order = descending order of the distinct keys
+                // stable descending order = descending order of the distinct keys (image, 63 - index); first on the 32-bit keys
+                k32[i] = (khi[i] & 0xffffffc0u) | (63u - (unsigned)lane);
             }
-            if (!(NB_ABLATE & 2)) nb_bitonic_sort<64, SW>(khi, klo);
+            if (!(NB_ABLATE & 2)) nb_bitonic_sort32<64, SW>(k32);
+            // verify: position `lane` holds element idx; its successor must be smaller in (image, 63 - index)
+            int idx[SW];
+            uint32_t img[SW];
+            bool redo = false;
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+                idx[i] = 63 - (int)(k32[i] & 63u);
+                img[i] = (uint32_t)__shfl((int)khi[i], idx[i], 64); // full image of the element now at this position
+            }
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+                const uint32_t nimg = (uint32_t)__shfl_down((int)img[i], 1, 64);
+                const int nidx = __shfl_down(idx[i], 1, 64);
+                const bool in_order = img[i] > nimg || (img[i] == nimg && idx[i] < nidx);
+                redo = redo || (__ballot(!in_order && lane < 63) != 0ull);
+            }
+            if (redo) { // two values that differ only in their low 6 bits: this group again, on the full keys (wave-uniform branch)
+                uint32_t klo[SW];
+#pragma unroll
+                for (int i = 0; i < SW; i++) klo[i] = 63u - (unsigned)lane;
+                nb_bitonic_sort<64, SW>(khi, klo);
+#pragma unroll
+                for (int i = 0; i < SW; i++) idx[i] = 63 - (int)klo[i];
+            }
 #pragma unroll
             for (int i = 0; i < SW; i++) {
                 const int edge = e0 + i;
                 if (live[i] && lane < q) {
-                    const int idx = 63 - (int)klo[i]; // original position of the element that belongs at position `lane`
-                    const int symk = (idx < q - 1) ? idx + 1 : 0;
+                    const int symk = (idx[i] < q - 1) ? idx[i] + 1 : 0; // idx: original position of the element that belongs at position `lane`
                     float2 pr;
-                    pr.x = pairs[edge * PST + 2 * idx];
+                    pr.x = pairs[edge * PST + 2 * idx[i]];
                     pr.y = __int_as_float((int)mulb[symk * q + t_vn_gf[edge]] << 2); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334, as a byte offset
                     *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * lane) = pr;
                 }

@@ -111,6 +111,30 @@ def test_ties_zeros_and_extremes(nb, code, ocode, orc):
         assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
 
 
+def test_values_that_differ_only_in_their_last_bits(nb, code, ocode, orc):
+    """The sort of phase B runs on 32-bit keys (value image without its low 6 bits | 63 - index), verifies the permutation against
+    the full (value, index) order and repeats a vector on the 64-bit keys when two values differ in nothing but those 6 bits.  Here
+    every channel vector is a handful of neighbouring floats (a few ulps apart, both signs), so nearly every vector takes the
+    repeat path: symbols, iteration counts, LLR and c2v bits must still equal the oracle's."""
+    rng = np.random.default_rng(11)
+    B = 6
+    base = np.array([1.0, -1.0, 0.37, -2.5, 1e-3, 7.0], np.float32)
+    Lch = np.empty((B, code.N, code.q - 1), np.float32)
+    for b in range(B):
+        ulps = rng.integers(0, 40, size=(code.N, code.q - 1)).astype(np.int32)
+        v = np.full((code.N, code.q - 1), base[b], np.float32).view(np.int32) + ulps  # same value, 0..39 ulps away
+        Lch[b] = v.view(np.float32)
+    Lch[3, ::2] *= -1.0
+    r = nb.Decoding_EMS(code, torch.from_numpy(Lch).cuda(), 2, 2, 4, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        want = orc.nb_ems_decode(ocode, Lch[b], 2, 2, 4, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+
+
 def test_full_size_batch_properties(nb, code, ocode, orc):
     """BASELINE config 5 size (16384 frames): a 32-frame oracle-checked block tiled 512 times; every tile must
     decode identically (frames are independent) and transmitted codewords that decode must be codewords."""
