@@ -195,10 +195,46 @@ template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32x4_dpp(
     else { NB_DPP_STEP("row_ror:8"); }
 #undef NB_DPP_STEP
 }
+// The same for partners 4 and 16 lanes away, which go through the LDS crossbar (ds_swizzle, no memory access): four swizzles in
+// flight, one wait.
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32x4_swz(uint32_t (&k)[4])
+{
+    static_assert(J == 4 || J == 16, "ds_swizzle SWAP patterns");
+    const unsigned long long nkm = ~nb_keepmax_mask(K, J);
+    uint32_t p0, p1, p2, p3;
+    unsigned long long m0, m1, m2, m3;
+#define NB_SWZ_STEP(PAT)                                                                                      \
+    asm volatile("ds_swizzle_b32 %4, %0 offset:swizzle(SWAP," PAT ")\n\t"                                      \
+                 "ds_swizzle_b32 %5, %1 offset:swizzle(SWAP," PAT ")\n\t"                                      \
+                 "ds_swizzle_b32 %6, %2 offset:swizzle(SWAP," PAT ")\n\t"                                      \
+                 "ds_swizzle_b32 %7, %3 offset:swizzle(SWAP," PAT ")\n\t"                                      \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                     \
+                 "v_cmp_gt_u32_e64 %8, %4, %0\n\t"                                                              \
+                 "v_cmp_gt_u32_e64 %9, %5, %1\n\t"                                                              \
+                 "v_cmp_gt_u32_e64 %10, %6, %2\n\t"                                                             \
+                 "v_cmp_gt_u32_e64 %11, %7, %3\n\t"                                                             \
+                 "s_xor_b64 %8, %8, %12\n\t"                                                                    \
+                 "s_xor_b64 %9, %9, %12\n\t"                                                                    \
+                 "s_xor_b64 %10, %10, %12\n\t"                                                                  \
+                 "s_xor_b64 %11, %11, %12\n\t"                                                                  \
+                 "v_cndmask_b32_e64 %0, %0, %4, %8\n\t"                                                         \
+                 "v_cndmask_b32_e64 %1, %1, %5, %9\n\t"                                                         \
+                 "v_cndmask_b32_e64 %2, %2, %6, %10\n\t"                                                        \
+                 "v_cndmask_b32_e64 %3, %3, %7, %11"                                                             \
+                 : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&s"(m0), "=&s"(m1), \
+                   "=&s"(m2), "=&s"(m3)                                                                         \
+                 : "s"(nkm)                                                                                     \
+                 : "scc", "memory")
+    if constexpr (J == 4) { NB_SWZ_STEP("4"); }
+    else { NB_SWZ_STEP("16"); }
+#undef NB_SWZ_STEP
+}
 template <int K, int J, int W> __device__ __forceinline__ void nb_bitonic_merge32(uint32_t (&k)[W])
 {
     if constexpr (W == 4 && (J == 1 || J == 2 || J == 8)) {
         nb_bitonic_step32x4_dpp<K, J>(k);
+    } else if constexpr (W == 4 && (J == 4 || J == 16)) {
+        nb_bitonic_step32x4_swz<K, J>(k);
     } else {
 #pragma unroll
         for (int i = 0; i < W; i++) nb_bitonic_step32<K, J>(k[i]);
