@@ -234,11 +234,22 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     unsigned long long hist = 0; // used by threads tid < NF
     unsigned done = 0;           // per-frame exit: frames of this workgroup that have stopped (workgroup-uniform)
     constexpr unsigned ALL = (1u << NF) - 1u;
+#ifdef QC_STAMPS
+    int nst = 0;
+    auto stamp = [&](unsigned long long v) { if (tid == 0 && nst < QC_STAMPS) a.stamps[(size_t)wg * QC_STAMPS + nst++] = v; };
+    stamp(((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4));
+    stamp(__builtin_amdgcn_s_memtime());
+#endif
     __syncthreads();
+#ifdef QC_STAMPS
+    stamp(__builtin_amdgcn_s_memtime());
+#endif
 
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
     auto vn_phase = [&](bool (&bad)[NF]) {
-        constexpr int CB = (CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1); // columns with reads in flight together
+        // columns with reads in flight together: all of them when that is at most 24 registers (a later batch's loads would
+        // queue behind the earlier batch's 6.2-cycle stores), else 3 or 2
+        constexpr int CB = (CPT * WV * NF <= 24) ? CPT : ((CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1));
         static_for<CPT / CB>([&](auto C0) {
             constexpr int c0 = decltype(C0)::value * CB;
             float R[CB][WV][NF];
@@ -389,7 +400,13 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         __builtin_amdgcn_s_setprio(QC_PRIO_VN);
         vn_phase(bad);
         if (HIST) flags_publish(bad, it);
+#ifdef QC_STAMPS
+        if (it == 20 && tid == 0) a.stamps[(size_t)wg * QC_STAMPS + 120] = __builtin_amdgcn_s_memtime(); // wave 0 reaches the VN barrier
+#endif
         __syncthreads();
+#ifdef QC_STAMPS
+        stamp(__builtin_amdgcn_s_memtime());
+#endif
         __builtin_amdgcn_s_setprio(QC_PRIO_CN);
         if (HIST) {
             (void)flags_collect(it);
@@ -416,7 +433,13 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
             }
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef QC_STAMPS
+        if (it == 20 && tid == 0) a.stamps[(size_t)wg * QC_STAMPS + 121] = __builtin_amdgcn_s_memtime(); // wave 0 reaches the CN barrier
+#endif
         __syncthreads();
+#ifdef QC_STAMPS
+        stamp(__builtin_amdgcn_s_memtime());
+#endif
     }
 
     // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -----------
@@ -431,6 +454,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         __syncthreads();
         flag = flags_collect(a.max_iter);
     }
+#ifdef QC_STAMPS
+    stamp(__builtin_amdgcn_s_memtime());
+#endif
     if (tid < NF && f0 + tid < F) {
         const bool stopped = HIST && ((done >> tid) & 1u);
         a.D[(size_t)L * Z * F + f0 + tid] = stopped ? 1 : flag;

@@ -13,10 +13,12 @@ using namespace cldpc;
 
 int main(int argc, char **argv)
 {
-    const int J = 4, L = 24, Z = 96, F = argc > 1 ? atoi(argv[1]) : 65536, iters = 50;
+    // usage: qc_phase_probe [F [stagger [J L Z path]]]
+    const int J = argc > 3 ? atoi(argv[3]) : 4, L = argc > 4 ? atoi(argv[4]) : 24, Z = argc > 5 ? atoi(argv[5]) : 96;
+    const int F = argc > 1 ? atoi(argv[1]) : 65536, iters = 50;
     g_qc_stagger = argc > 2 ? atoi(argv[2]) : 0;
     std::vector<int> H(J * L);
-    FILE *fp = fopen("data/bldpc/J4_L24_Z96_BlockH.txt", "r");
+    FILE *fp = fopen(argc > 6 ? argv[6] : "data/bldpc/J4_L24_Z96_BlockH.txt", "r");
     if (!fp) return 1;
     for (int &h : H)
         if (fscanf(fp, "%d", &h) != 1) return 1;
@@ -71,6 +73,15 @@ int main(int argc, char **argv)
             for (int it = 1; it < 49; it++) per[it] += (double)(s[3 + 2 * it] - s[3 + 2 * (it - 1)]);
         }
         printf("per workgroup: prologue %.0f cycles, first VN phase %.0f, loop (49 iterations) %.0f, final VN + outputs %.0f\n", pro / nWG, first / nWG, loop / nWG, epi / nWG);
+        {
+            double vnw = 0, cnw = 0; int n = 0; // wave 0's own arrival at the barriers of iteration 20 (k_qc only: slots 120, 121)
+            for (int w = 0; w < nWG; w++) {
+                const unsigned long long *s = &st[(size_t)w * QC_STAMPS];
+                if (!s[120]) continue;
+                vnw += (double)(s[3 + 2 * 19] - s[120]); cnw += (double)(s[4 + 2 * 19] - s[121]); n++;
+            }
+            if (n) printf("iteration 20: wave 0 waits %.0f cycles at the VN barrier, %.0f at the CN barrier\n", vnw / n, cnw / n);
+        }
         printf("iteration period by iteration:");
         for (int it = 1; it < 49; it++) printf(" %.0f", per[it] / nWG);
         printf("\n");
