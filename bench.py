@@ -144,7 +144,23 @@ def nb_cpu_baseline(snr, nframes, method=0):
     from oracle import pyoracle as orc
     ref = orc.ref_binary()
     if ref is None:
-        return None
+        # the built reference binary did not travel: time the restatement (oracle/nbldpc_oracle.c) on the same frames, one core
+        nbd = os.path.join(ROOT, "data", "nb")
+        ocode = orc.NBCode(os.path.join(nbd, "BDS.576.288.GF.64.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
+        cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
+        seed = np.array([173, 173, 173], np.int32)
+        n = (nframes or 100) * (1 if method == 0 else 3)
+        sigma = orc.nb_sigma(snr, 0.5)
+        Lch = [orc.nb_channel(ocode, cw, seed, sigma)[1] for _ in range(n)]
+        t0 = time.perf_counter()
+        its = 0
+        for L in Lch:
+            r = orc.nb_ems_decode(ocode, L, 2, 2, 20) if method == 0 else orc.nb_tmm_decode(ocode, L, 20, layered=(method == 3))
+            its += r["it"]
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "codewords/s", "cores": 1, "kind": "port",
+                "sample": "first %d frames of the same seed-173 stream at Eb/N0 %.1f dB, oracle/nbldpc_oracle.c (the reference binary "
+                          "oracle/_ref/nb_ref is not present), mean %.2f iterations, %.1f s" % (n, snr, its / n, dt)}
     nframes = nframes or 300  # ~33 frames/s at 3 dB -> ~10 s
     nframes = nframes * (1 if method == 0 else 3)  # the trellis decoders converge in fewer, cheaper iterations
     out = subprocess.check_output([ref, "time", str(snr), str(nframes), str(method)], cwd=os.path.join(ROOT, "data", "nb")).decode()
