@@ -247,9 +247,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
     auto vn_phase = [&](bool (&bad)[NF]) {
-        // columns with reads in flight together: all of them when that is at most 24 registers (a later batch's loads would
-        // queue behind the earlier batch's 6.2-cycle stores), else 3 or 2
-        constexpr int CB = (CPT * WV * NF <= 24) ? CPT : ((CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1));
+        constexpr int CB = (CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1); // columns with reads in flight together
         static_for<CPT / CB>([&](auto C0) {
             constexpr int c0 = decltype(C0)::value * CB;
             float R[CB][WV][NF];
@@ -341,12 +339,6 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
     // ---- iterations 1 .. max_iter-1: VN, CN --------------------------------------------------
     // One check row with exactly W edges (W <= WC; W < WC only where the row weight is wave-uniform, i.e. Z is whole waves:
     // J32_L64_Z64 has rows of 5, 6 and 7 edges).  Rows lighter than W read the +inf slot in their padding positions.
-    // With two rows per thread the S values of BOTH rows are requested before the first row's arithmetic: otherwise the second
-    // row's loads queue behind the first row's 6.2-cycle stores and the VALU idles while they drain (one workgroup per CU here:
-    // nobody else fills that gap).  PRE = the slots every row has.
-    constexpr bool ROWU_ = (Z % 64 == 0) && WC >= 4;
-    constexpr int PRE = (RPT == 2 && RPT * WC * NF <= 32) ? (ROWU_ ? WC - 2 : WC) : 0;
-    float Spre[PRE ? RPT : 1][PRE ? PRE : 1][NF];
     auto s_load = [&](float (&d)[NF], int rr, int pp) {
         if (UNPACKED) lds_ld<NF>(d, lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
         else lds_ld<NF>(d, lds, (int)((pp & 1) ? (saddr[rr][pp / 2] >> 16) : (saddr[rr][pp / 2] & 0xffffu)) * MSG);
@@ -356,14 +348,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         {
             float Sv[W][NF];
 #pragma unroll
-            for (int pp = 0; pp < W; pp++) {
-                if (pp < PRE) {
-#pragma unroll
-                    for (int v = 0; v < NF; v++) Sv[pp][v] = Spre[PRE ? rr : 0][PRE ? pp : 0][v];
-                } else {
-                    s_load(Sv[pp], rr, pp);
-                }
-            }
+            for (int pp = 0; pp < W; pp++) s_load(Sv[pp], rr, pp);
 #pragma unroll
             for (int pp = 0; pp < W; pp++)
 #pragma unroll
@@ -414,15 +399,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         }
 
         // CN phase (LDPC_Decoder.cu:279-314)
-        if (PRE) {
-#pragma unroll
-            for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-                for (int pp = 0; pp < PRE; pp++) s_load(Spre[PRE ? rr : 0][PRE ? pp : 0], rr, pp);
-        }
         static_for<RPT>([&](auto RR) {
             constexpr int rr = decltype(RR)::value;
-            constexpr bool ROWU = ROWU_; // the row, hence its weight, is wave-uniform: a scalar branch picks the exact body
+            constexpr bool ROWU = (Z % 64 == 0) && WC >= 4; // the row, hence its weight, is wave-uniform: a scalar branch picks the exact body
             if constexpr (ROWU) {
                 const int wu = __builtin_amdgcn_readfirstlane(wrv[rr]);
                 if (wu <= WC - 2) cn_row(RR, std::integral_constant<int, WC - 2>{});
