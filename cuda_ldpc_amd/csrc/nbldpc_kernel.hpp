@@ -139,112 +139,72 @@ template <int K, int W> __device__ __forceinline__ void nb_bitonic_sort(uint32_t
 }
 
 // The same network on ONE 32-bit key per lane: the order-preserving image of the value with its low 6 bits replaced by
-// 63 - index.  Half the instructions of the 64-bit step (one partner fetch, one v_cmp, one select) -- and exact only when no two
-// values of the vector differ in nothing but those 6 bits, so the caller VERIFIES the resulting permutation against the full
-// (value, index) order and repeats the vector on the 64-bit network when a neighbouring pair is out of order (the keys are
-// pairwise distinct, so the permutation whose neighbours are all in order is the one the stable sort produces).
-template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32(uint32_t &k)
+// 63 - index.  Exact only when no two values of the vector differ in nothing but those 6 bits, so the caller VERIFIES the
+// resulting permutation against the full (value, index) order and repeats the vector on the 64-bit network when a neighbouring
+// pair is out of order (the keys are pairwise distinct, so the permutation whose neighbours are all in order is the one the
+// stable sort produces).
+// One compare-exchange = partner fetch + v_med3_u32(k, partner, B) with B = 0xffffffff in the lanes that keep the larger key
+// (the median of {k, partner, max} is the larger one) and 0 in the others (the smaller one): no compare, no mask, no select.  B is
+// the same for the four sorts in flight; the 21 keep-max lane patterns of the network are one bit each of a per-lane word
+// (nb_keepmax_word), so a step costs one v_bfe_i32 and, per sort, a v_mov_b32_dpp (or ds_swizzle) and a v_med3_u32.
+__host__ __device__ constexpr int nb_step_index(int K, int J)
 {
-    constexpr unsigned long long KM = nb_keepmax_mask(K, J);
-    uint32_t pk;
+    int n = 0; // steps in execution order: K = 2, 4, ..., 64; inside a merge J = K/2, K/4, ..., 1
+    for (int k = 2; k < K; k *= 2)
+        for (int j = k / 2; j >= 1; j /= 2) n++;
+    for (int j = K / 2; j > J; j /= 2) n++;
+    return n;
+}
+__device__ __forceinline__ uint32_t nb_keepmax_word(int lane)
+{
+    uint32_t w = 0;
+    for (int K = 2; K <= 64; K *= 2)
+        for (int J = K / 2; J >= 1; J /= 2) {
+            const bool lower = (lane & J) == 0, up = (K >= 64) ? true : ((lane & K) == 0);
+            if (lower == up) w |= 1u << nb_step_index(K, J);
+        }
+    return w;
+}
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32x4(uint32_t (&k)[4], uint32_t kmw)
+{
+    const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int)kmw, nb_step_index(K, J), 1); // 0xffffffff where this lane keeps the larger key
     if constexpr (J == 1 || J == 2 || J == 8) {
-        constexpr int CTRL = (J == 1) ? 0xB1 : (J == 2) ? 0x4E : 0x128; // quad_perm [1,0,3,2], [2,3,0,1], row_ror:8
-        pk = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, 0xf, 0xf, false);
-    } else if constexpr (J < 32) {
-        pk = (uint32_t)__builtin_amdgcn_ds_swizzle((int)k, (J << 10) | 0x1f);
-    } else {
-        pk = (uint32_t)__shfl_xor((int)k, 32, 64);
-    }
-    const bool take = __builtin_amdgcn_inverse_ballot_w64(~(__builtin_amdgcn_ballot_w64(pk > k) ^ KM));
-    k = take ? pk : k;
-}
-// Four sorts through one DPP step, written out: the compiler's version spends 7 issue slots per sort (a copy for the DPP's tied
-// operand, s_nop hazard pads, everything through VCC); here the four sorts interleave so that every hazard distance is met by
-// useful instructions and each compare keeps its own SGPR pair: 4 x (v_mov_b32_dpp, v_cmp, s_xor, v_cndmask).
-template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32x4_dpp(uint32_t (&k)[4])
-{
-    static_assert(J == 1 || J == 2 || J == 8, "partners inside a row of 16");
-    constexpr unsigned long long NKM = ~nb_keepmax_mask(K, J); // take = (pk > k) XNOR keepmax = (pk > k) XOR ~keepmax
-    const unsigned long long nkm = NKM;
-    uint32_t p0, p1, p2, p3;
-    unsigned long long m0, m1, m2, m3;
-#define NB_DPP_STEP(CTRL)                                                                                     \
-    asm volatile("s_nop 1\n\t" /* a DPP source written by the VALU instruction just before needs 2 wait states */  \
-                 "v_mov_b32_dpp %4, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
-                 "v_mov_b32_dpp %5, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
-                 "v_mov_b32_dpp %6, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
-                 "v_mov_b32_dpp %7, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
-                 "v_cmp_gt_u32_e64 %8, %4, %0\n\t"                                                              \
-                 "v_cmp_gt_u32_e64 %9, %5, %1\n\t"                                                              \
-                 "v_cmp_gt_u32_e64 %10, %6, %2\n\t"                                                             \
-                 "v_cmp_gt_u32_e64 %11, %7, %3\n\t"                                                             \
-                 "s_xor_b64 %8, %8, %12\n\t"                                                                    \
-                 "s_xor_b64 %9, %9, %12\n\t"                                                                    \
-                 "s_xor_b64 %10, %10, %12\n\t"                                                                  \
-                 "s_xor_b64 %11, %11, %12\n\t"                                                                  \
-                 "v_cndmask_b32_e64 %0, %0, %4, %8\n\t"                                                         \
-                 "v_cndmask_b32_e64 %1, %1, %5, %9\n\t"                                                         \
-                 "v_cndmask_b32_e64 %2, %2, %6, %10\n\t"                                                        \
-                 "v_cndmask_b32_e64 %3, %3, %7, %11"                                                             \
-                 : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&s"(m0), "=&s"(m1), \
-                   "=&s"(m2), "=&s"(m3)                                                                         \
-                 : "s"(nkm)                                                                                     \
-                 : "scc")
-    if constexpr (J == 1) { NB_DPP_STEP("quad_perm:[1,0,3,2]"); }
-    else if constexpr (J == 2) { NB_DPP_STEP("quad_perm:[2,3,0,1]"); }
-    else { NB_DPP_STEP("row_ror:8"); }
+        // the four sorts interleaved so that every hazard distance (a DPP source written by the VALU needs 2 wait states) is met
+        uint32_t p0, p1, p2, p3;
+#define NB_DPP_STEP(CTRL)                                                                                       \
+    asm volatile("s_nop 1\n\t"                                                                                   \
+                 "v_mov_b32_dpp %4, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                 "v_mov_b32_dpp %5, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                 "v_mov_b32_dpp %6, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                 "v_mov_b32_dpp %7, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                 "v_med3_u32 %0, %0, %4, %8\n\t"                                                                  \
+                 "v_med3_u32 %1, %1, %5, %8\n\t"                                                                  \
+                 "v_med3_u32 %2, %2, %6, %8\n\t"                                                                  \
+                 "v_med3_u32 %3, %3, %7, %8"                                                                       \
+                 : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(B))
+        if constexpr (J == 1) { NB_DPP_STEP("quad_perm:[1,0,3,2]"); }
+        else if constexpr (J == 2) { NB_DPP_STEP("quad_perm:[2,3,0,1]"); }
+        else { NB_DPP_STEP("row_ror:8"); }
 #undef NB_DPP_STEP
-}
-// The same for partners 4 and 16 lanes away, which go through the LDS crossbar (ds_swizzle, no memory access): four swizzles in
-// flight, one wait.
-template <int K, int J> __device__ __forceinline__ void nb_bitonic_step32x4_swz(uint32_t (&k)[4])
-{
-    static_assert(J == 4 || J == 16, "ds_swizzle SWAP patterns");
-    const unsigned long long nkm = ~nb_keepmax_mask(K, J);
-    uint32_t p0, p1, p2, p3;
-    unsigned long long m0, m1, m2, m3;
-#define NB_SWZ_STEP(PAT)                                                                                      \
-    asm volatile("ds_swizzle_b32 %4, %0 offset:swizzle(SWAP," PAT ")\n\t"                                      \
-                 "ds_swizzle_b32 %5, %1 offset:swizzle(SWAP," PAT ")\n\t"                                      \
-                 "ds_swizzle_b32 %6, %2 offset:swizzle(SWAP," PAT ")\n\t"                                      \
-                 "ds_swizzle_b32 %7, %3 offset:swizzle(SWAP," PAT ")\n\t"                                      \
-                 "s_waitcnt lgkmcnt(0)\n\t"                                                                     \
-                 "v_cmp_gt_u32_e64 %8, %4, %0\n\t"                                                              \
-                 "v_cmp_gt_u32_e64 %9, %5, %1\n\t"                                                              \
-                 "v_cmp_gt_u32_e64 %10, %6, %2\n\t"                                                             \
-                 "v_cmp_gt_u32_e64 %11, %7, %3\n\t"                                                             \
-                 "s_xor_b64 %8, %8, %12\n\t"                                                                    \
-                 "s_xor_b64 %9, %9, %12\n\t"                                                                    \
-                 "s_xor_b64 %10, %10, %12\n\t"                                                                  \
-                 "s_xor_b64 %11, %11, %12\n\t"                                                                  \
-                 "v_cndmask_b32_e64 %0, %0, %4, %8\n\t"                                                         \
-                 "v_cndmask_b32_e64 %1, %1, %5, %9\n\t"                                                         \
-                 "v_cndmask_b32_e64 %2, %2, %6, %10\n\t"                                                        \
-                 "v_cndmask_b32_e64 %3, %3, %7, %11"                                                             \
-                 : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&s"(m0), "=&s"(m1), \
-                   "=&s"(m2), "=&s"(m3)                                                                         \
-                 : "s"(nkm)                                                                                     \
-                 : "scc", "memory")
-    if constexpr (J == 4) { NB_SWZ_STEP("4"); }
-    else { NB_SWZ_STEP("16"); }
-#undef NB_SWZ_STEP
-}
-template <int K, int J, int W> __device__ __forceinline__ void nb_bitonic_merge32(uint32_t (&k)[W])
-{
-    if constexpr (W == 4 && (J == 1 || J == 2 || J == 8)) {
-        nb_bitonic_step32x4_dpp<K, J>(k);
-    } else if constexpr (W == 4 && (J == 4 || J == 16)) {
-        nb_bitonic_step32x4_swz<K, J>(k);
     } else {
 #pragma unroll
-        for (int i = 0; i < W; i++) nb_bitonic_step32<K, J>(k[i]);
+        for (int i = 0; i < 4; i++) {
+            uint32_t pk;
+            if constexpr (J < 32) pk = (uint32_t)__builtin_amdgcn_ds_swizzle((int)k[i], (J << 10) | 0x1f); // partners 4 and 16 lanes away: LDS crossbar
+            else pk = (uint32_t)__shfl_xor((int)k[i], 32, 64);
+            asm("v_med3_u32 %0, %1, %2, %3" : "=v"(k[i]) : "v"(k[i]), "v"(pk), "v"(B));
+        }
     }
-    if constexpr (J > 1) nb_bitonic_merge32<K, J / 2, W>(k);
 }
-template <int K, int W> __device__ __forceinline__ void nb_bitonic_sort32(uint32_t (&k)[W])
+template <int K, int J> __device__ __forceinline__ void nb_bitonic_merge32(uint32_t (&k)[4], uint32_t kmw)
 {
-    if constexpr (K > 2) nb_bitonic_sort32<K / 2, W>(k);
-    nb_bitonic_merge32<K, K / 2, W>(k);
+    nb_bitonic_step32x4<K, J>(k, kmw);
+    if constexpr (J > 1) nb_bitonic_merge32<K, J / 2>(k, kmw);
+}
+template <int K> __device__ __forceinline__ void nb_bitonic_sort32(uint32_t (&k)[4], uint32_t kmw)
+{
+    if constexpr (K > 2) nb_bitonic_sort32<K / 2>(k, kmw);
+    nb_bitonic_merge32<K, K / 2>(k, kmw);
 }
 
 template <int NACT> struct NbCn {
@@ -256,6 +216,14 @@ template <int NACT> struct NbCn {
     const float *pairs;
 };
 __device__ __forceinline__ float &nb_e(char *E, int sym4) { return *reinterpret_cast<float *>(E + sym4); }
+// E[sym] = max(E[sym], v) as ONE LDS instruction instead of load / compare / select / store.  Equal to the reference's
+// `if (s > E[sym]) E[sym] = s` (LDPC_Decoder.cpp:322-325) here: a running sum that starts at +0 and only adds and subtracts is
+// never -0 (the one case in which the LDS maximum and the strict `>` differ), and there are no NaNs.
+__device__ __forceinline__ void nb_ds_max(char *E, int sym4, float v)
+{
+    typedef __attribute__((address_space(3))) char lds_byte;
+    asm volatile("ds_max_f32 %0, %1" : : "v"((lds_byte *)(E + sym4)), "v"(v) : "memory");
+}
 
 // Sub-walk entered with diff == 1 (one deviation already spent) at depth D: exactly one leaf (all
 // remaining positions at k = 0), then on the way back every position tries k = 1, exceeds Nc = 1
@@ -321,7 +289,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
         for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (1 + i));
 #pragma unroll 1
         for (int k0 = 1; k0 < Q; k0 += CH) {
-            float v[CH], sl[CH], ev[CH];
+            float v[CH], sl[CH];
             int sy[CH];
 #pragma unroll
             for (int i = 0; i < CH; i++) {
@@ -334,8 +302,6 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
                 for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (kn + i));
             }
 #pragma unroll
-            for (int i = 0; i < CH; i++) ev[i] = nb_e(c.E, sy[i]);
-#pragma unroll
             for (int i = 0; i < CH; i++) {
                 int unused;
                 c.s = c.s + v[i];
@@ -343,7 +309,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
                 c.s = c.s - v[i];
             }
 #pragma unroll
-            for (int i = 0; i < CH; i++) nb_e(c.E, sy[i]) = (sl[i] > ev[i]) ? sl[i] : ev[i]; // :322-325, as a select: no exec juggling
+            for (int i = 0; i < CH; i++) nb_ds_max(c.E, sy[i], sl[i]); // :322-325
         }
     }
 }
@@ -352,8 +318,7 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 template <int D, int NACT> __device__ void nb_conf(NbCn<NACT> &c, int symbase, int diff, int Nm, int Nc)
 {
     if constexpr (D == NACT) {
-        float &e = nb_e(c.E, symbase);
-        if (c.s > e) e = c.s;
+        nb_ds_max(c.E, symbase, c.s); // :322-325
     } else {
         for (int k = 0; k < Nm; k++) {
             float v;
@@ -546,6 +511,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         }
         // ---- B: stable descending sort of every v2c vector (:17-36, :253-269) -----------------
         constexpr int SW = 4; // sorts in flight per wave
+        const uint32_t kmw = nb_keepmax_word(lane);
         for (int e0 = wave * SW; e0 < NE; e0 += nwaves * SW) {
             uint32_t khi[SW], k32[SW];
             bool live[SW];
@@ -560,7 +526,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
                 // stable descending order = descending order of the distinct keys (image, 63 - index); first on the 32-bit keys
                 k32[i] = (khi[i] & 0xffffffc0u) | (63u - (unsigned)lane);
             }
-            if (!(NB_ABLATE & 2)) nb_bitonic_sort32<64, SW>(k32);
+            if (!(NB_ABLATE & 2)) nb_bitonic_sort32<64>(k32, kmw);
             // verify: position `lane` holds element idx; its successor must be smaller in (image, 63 - index)
             int idx[SW];
             uint32_t img[SW];
