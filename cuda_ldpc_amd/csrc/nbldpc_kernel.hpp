@@ -538,8 +538,9 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
             }
 #pragma unroll
             for (int i = 0; i < SW; i++) {
-                const uint32_t nimg = (uint32_t)__shfl_down((int)img[i], 1, 64);
-                const int nidx = __shfl_down(idx[i], 1, 64);
+                // the successor's (image, index): DPP wave_shl:1 (lane i reads lane i + 1; lane 63 is not looked at)
+                const uint32_t nimg = (uint32_t)__builtin_amdgcn_update_dpp((int)img[i], (int)img[i], 0x130, 0xf, 0xf, false);
+                const int nidx = __builtin_amdgcn_update_dpp(idx[i], idx[i], 0x130, 0xf, 0xf, false);
                 const bool in_order = img[i] > nimg || (img[i] == nimg && idx[i] < nidx);
                 redo = redo || (__ballot(!in_order && lane < 63) != 0ull);
             }
