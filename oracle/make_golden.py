@@ -83,6 +83,29 @@ def make_nb(method=0, tag="nb_ref"):
     np.savetxt(os.path.join(ROOT, "data", "nb", "codeword_bds_gf64.txt"), d["cw"][None, :], fmt="%d")
 
 
+def make_nb_gf256():
+    """The reference's GF(256) code LDPC_N96_K48_GF256_d1_exp.txt (12 symbols, 6 checks) through its own Decoding_EMS
+    (oracle/_ref/nb_ref_gf256: define.h's Matrixfile / GFQ edited at build time, all-zero codeword): 12 frames per Eb/N0."""
+    ref = os.path.join(HERE, "_ref", "nb_ref_gf256")
+    if not os.path.exists(ref):
+        print("oracle/_ref/nb_ref_gf256 missing -> GF(256) golden not regenerated")
+        return
+    for snr in (2.0, 4.0, 6.0):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "d.bin")
+            subprocess.check_call([ref, "dump", str(snr), "12", out, "0"], cwd=os.path.join(ROOT, "data", "nb"), stdout=subprocess.DEVNULL)
+            d = parse_nb_dump(out)
+        recs = d["recs"]
+        assert d["q"] == 256 and d["N"] == 12 and d["M"] == 6
+        np.savez_compressed(
+            os.path.join(GOLD, "nb_ref_gf256_%gdB.npz" % snr),
+            snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"],
+            rx=np.stack([r["rx"] for r in recs]), out=np.stack([r["out"] for r in recs]),
+            it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
+            Lch=np.stack([r["Lch"] for r in recs]), LLR=np.stack([r["LLR"] for r in recs]), c2v=np.stack([r["c2v"] for r in recs]))
+        print("NB GF(256) %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+
+
 # (file, J, L, Z, F, Es/N0 dB, literal table?, hash recorded in SURVEY.md 8c or None)
 BIN_CASES = [
     ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 3.0, False, 0x05A41534),
@@ -115,3 +138,4 @@ if __name__ == "__main__":
     make_nb()
     make_nb(1, "nb_ref_tmm")
     make_nb(3, "nb_ref_ltmm")
+    make_nb_gf256()

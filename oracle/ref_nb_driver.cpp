@@ -64,7 +64,11 @@ int main(int argc, char **argv)
     CComplex *CComplex_sym = (CComplex *)malloc(H->bit_length * sizeof(CComplex));
     for (int i = 0; i < H->Variablenode_num; i++)
         for (int j = 0; j < H->q_bit; j++)
+#ifdef NB_REF_ZERO_CW /* codes other than the GF(64) one of codeword_test.h: the all-zero word, a codeword of every linear code */
+            CodeWord_bit[i * H->q_bit + j] = 0;
+#else
             CodeWord_bit[i * H->q_bit + j] = (CodeWord_sym_test[i] & (1 << j)) >> j;
+#endif
     BitToSym(H, CodeWord_sym, CodeWord_bit);
     Modulate(H, CONSTELLATION, CComplex_sym, CodeWord_bit);
 

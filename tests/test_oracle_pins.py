@@ -127,6 +127,30 @@ def test_nb_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr):
             assert np.array_equal(r["c2v"].view(np.uint32), g["full_c2v"][i].view(np.uint32))
 
 
+@pytest.mark.parametrize("snr", [2, 4, 6])
+def test_nb_gf256_oracle_bit_exact_vs_reference_dump(orc, snr):
+    """GF(256): the reference's own Decoding_EMS on its code LDPC_N96_K48_GF256_d1_exp.txt (oracle/_ref/nb_ref_gf256: define.h's
+    Matrixfile / GFQ edited at build time; all-zero codeword) against the restatement -- channel stream, L_ch, symbols, iteration
+    counts, return flags and the full final LLR / L_c2v bits of all 36 frames (1 ... 20 iterations deep)."""
+    nbd = os.path.join(DATA, "nb")
+    c = orc.NBCode(os.path.join(nbd, "LDPC_N96_K48_GF256_d1_exp.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.256.txt"))
+    assert (c.N, c.M, c.q, c.dv, c.dc) == (12, 6, 256, 2, 4)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_gf256_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    assert np.float32(orc.nb_sigma(float(g["snr"]), c.rate)) == np.float32(sigma) and np.float32(c.rate) == np.float32(g["rate"])
+    assert not g["cw"].any()
+    seed = np.array([173, 173, 173], np.int32)
+    for fr in range(g["rx"].shape[0]):
+        rx, Lch = orc.nb_channel(c, g["cw"], seed, sigma)
+        assert np.array_equal(rx.view(np.uint32), g["rx"][fr].view(np.uint32)), "rx frame %d" % fr
+        assert np.array_equal(Lch.view(np.uint32), g["Lch"][fr].view(np.uint32)), "L_ch frame %d" % fr
+        r = orc.nb_ems_decode(c, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]), "frame %d" % fr
+        assert np.array_equal(r["out"], g["out"][fr])
+        assert np.array_equal(r["LLR"].view(np.uint32), g["LLR"][fr].view(np.uint32)), "LLR frame %d" % fr
+        assert np.array_equal(r["c2v"].view(np.uint32), g["c2v"][fr].view(np.uint32)), "c2v frame %d" % fr
+
+
 @pytest.mark.parametrize("snr", [2, 3, 5])
 @pytest.mark.parametrize("layered", [False, True])
 def test_nb_tmm_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr, layered):
