@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "nbldpc_kernel.hpp"
 #include "nbldpc_tmm_kernel.hpp"
+#include "nbldpc_wide_kernel.hpp"
 
 using namespace cldpc;
 
@@ -127,6 +128,8 @@ static int up(void **dst, const void *src, size_t bytes)
 using NbKernel = void (*)(NbArgs);
 static NbKernel nb_kernel(int q, int dv)
 {
+    if (q == 256) return k_nb_ems_wide<256, 1024>; // fields wider than a wavefront (nbldpc_wide_kernel.hpp)
+    if (q == 128) return k_nb_ems_wide<128, 1024>;
     if (q == 64) return dv <= 2 ? k_nb_ems<64, 2, nb_threads(64)> : k_nb_ems<64, kNbMaxDv, nb_threads(64)>;
     if (q == 32) return dv <= 2 ? k_nb_ems<32, 2, nb_threads(32)> : k_nb_ems<32, kNbMaxDv, nb_threads(32)>;
     return dv <= 2 ? k_nb_ems<16, 2, nb_threads(16)> : k_nb_ems<16, kNbMaxDv, nb_threads(16)>;
@@ -145,10 +148,11 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     int m = 0;
     while ((1 << m) < q) m++;
     if (N <= 0 || M <= 0 || q < 4 || (1 << m) != q) return fail(NBLDPC_EINVAL, "bad dimensions N=%d M=%d q=%d", N, M, q);
-    if (q != 16 && q != 32 && q != 64) return fail(NBLDPC_EUNSUPPORTED, "fused EMS kernel supports q in {16,32,64} (got %d)", q);
+    if (q != 16 && q != 32 && q != 64 && q != 128 && q != 256)
+        return fail(NBLDPC_EUNSUPPORTED, "fused EMS kernels support q in {16,32,64,128,256} (got %d)", q);
     if (dv > kNbMaxDv || dc > kNbMaxW) return fail(NBLDPC_EUNSUPPORTED, "dvmax=%d (<= %d) / dcmax=%d (<= %d) unsupported", dv, kNbMaxDv, dc, kNbMaxW);
     if (M * dc > nb_threads(q) || M > nb_threads(q)) return fail(NBLDPC_EUNSUPPORTED, "M*dcmax = %d exceeds %d check-edge threads per frame", M * dc, nb_threads(q));
-    const size_t lds = nb_lds_bytes(N, M, q, dv, dc);
+    const size_t lds = q > 64 ? nb_wide_lds_bytes(N, M, q, dv, dc, nb_threads(q)) : nb_lds_bytes(N, M, q, dv, dc);
     if (lds > 160 * 1024) return fail(NBLDPC_EUNSUPPORTED, "per-frame message state %zu B exceeds the 160 KiB LDS of one CU", lds);
     // cross indices: index_in_CN / index_in_VN (LDPC_Decoder.cpp:106-130), first match
     std::vector<int> vn_thr((size_t)N * dv, 0), cn_src((size_t)M * dc, 0);
@@ -221,7 +225,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         for (int i = 0; i < M; i++) lbegin[level[i] + 1]++;
         for (int l = 0; l < levels; l++) lbegin[l + 1] += lbegin[l];
         c->levels = levels;
-        c->tmm_ok = inv_ok && dc <= kTmmMaxW && levels <= 63 && M <= kTmmThreads &&
+        c->tmm_ok = q <= 64 && inv_ok && dc <= kTmmMaxW && levels <= 63 && M <= kTmmThreads && // the trellis kernels keep a vector in one wave
                     tmm_lds_bytes(N, M, q, dv, dc, false) <= 160 * 1024;
         if (c->tmm_ok) {
             if (!r) r = up((void **)&c->d_cn_hinv, hinv.data(), hinv.size() * sizeof(int));

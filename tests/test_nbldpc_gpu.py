@@ -135,6 +135,55 @@ def test_values_that_differ_only_in_their_last_bits(nb, code, ocode, orc):
         assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
 
 
+@pytest.mark.parametrize("snr", [2, 4, 6])
+def test_gf256_matches_reference_dump(nb, orc, snr):
+    """GF(256), the reference's code LDPC_N96_K48_GF256_d1_exp.txt (12 symbols, 6 checks): a message vector spans four waves
+    (k_nb_ems_wide).  Inputs = the reference's channel samples; Demodulate, symbols, iteration counts, return flags and the final
+    LLR / L_c2v bits vs the reference's own Decoding_EMS built for GFQ 256 (tests/golden/nb_ref_gf256_*.npz, 36 frames)."""
+    mul, _, _ = nb.GFInitial(256, os.path.join(NB, "GF", "Arith.Table.GF.256.txt"))
+    code = nb.NBCode(os.path.join(NB, "LDPC_N96_K48_GF256_d1_exp.txt"), mul)
+    assert (code.N, code.M, code.q) == (12, 6, 256)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_gf256_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), sigma)
+    assert np.array_equal(Lch.cpu().numpy().view(np.uint32), g["Lch"].view(np.uint32))
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+    assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+    assert np.array_equal(r["LLR"].cpu().numpy().view(np.uint32), g["LLR"].view(np.uint32))
+    assert np.array_equal(r["L_c2v"].cpu().numpy().view(np.uint32), g["c2v"].view(np.uint32))
+
+
+def test_gf256_ties_and_batch_independence(nb, orc):
+    """GF(256) on inputs full of exact ties and signed zeros (first-maximum rule and stable order across the four waves of a
+    vector) against the oracle, and a 2 048-frame batch whose tiles must decode identically."""
+    nbd = NB
+    mul, _, _ = nb.GFInitial(256, os.path.join(nbd, "GF", "Arith.Table.GF.256.txt"))
+    code = nb.NBCode(os.path.join(nbd, "LDPC_N96_K48_GF256_d1_exp.txt"), mul)
+    ocode = orc.NBCode(os.path.join(nbd, "LDPC_N96_K48_GF256_d1_exp.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.256.txt"))
+    rng = np.random.default_rng(5)
+    B = 4
+    Lch = rng.integers(-2, 3, size=(B, code.N, code.q - 1)).astype(np.float32)
+    Lch[0, :, ::7] = -0.0
+    Lch[1] *= 1e30
+    r = nb.Decoding_EMS(code, torch.from_numpy(Lch).cuda(), 2, 2, 3, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        want = orc.nb_ems_decode(ocode, Lch[b], 2, 2, 3, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+    g = np.load(os.path.join(GOLDEN, "nb_ref_gf256_4dB.npz"))
+    Lt = torch.from_numpy(g["Lch"][:8]).cuda().repeat(256, 1, 1).contiguous()
+    r = nb.Decoding_EMS(code, Lt, 2, 2, int(g["maxit"]))
+    torch.cuda.synchronize()
+    out = r["DecodeOutput"].view(256, 8, code.N)
+    assert bool((out == out[:1]).all()) and np.array_equal(out[0].cpu().numpy(), g["out"][:8])
+    assert np.array_equal(r["iter_number"].view(256, 8)[0].cpu().numpy(), g["it"][:8])
+
+
 def test_full_size_batch_properties(nb, code, ocode, orc):
     """BASELINE config 5 size (16384 frames): a 32-frame oracle-checked block tiled 512 times; every tile must
     decode identically (frames are independent) and transmitted codewords that decode must be codewords."""
