@@ -46,6 +46,8 @@ WORKLOADS = {
     # the reference's other decoder_method values on the same code (define.h:37): 1 trellis min-max, 3 layered trellis min-max
     "NB_BDS_GF64_TMM": ("BDS.576.288.GF.64.txt", 0, 0, 1, 16384, 3.0, 20),
     "NB_BDS_GF64_LTMM": ("BDS.576.288.GF.64.txt", 0, 0, 3, 16384, 3.0, 20),
+    # the reference's GF(256) code (12 symbols, 6 checks; second field = q): a message vector spans four waves (k_nb_ems_wide)
+    "NB_N96_GF256": ("LDPC_N96_K48_GF256_d1_exp.txt", 256, 0, 0, 8192, 4.0, 20),
 }
 
 
@@ -137,20 +139,23 @@ def cpu_threads():
     return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
-def nb_cpu_baseline(snr, nframes, method=0):
+def nb_cpu_baseline(snr, nframes, method=0, q=64, matrix="BDS.576.288.GF.64.txt"):
     """The REFERENCE's own CPU decoder (oracle/_ref/nb_ref, built from /root/reference/myNBLDPC/src/*.cpp;
     single-threaded like the reference's THREAD_NUM 1) on the first frames of the same stream."""
     import subprocess
     from oracle import pyoracle as orc
     ref = orc.ref_binary()
+    if q == 256:  # the reference built for GFQ 256 / LDPC_N96_K48_GF256_d1_exp.txt (oracle/Makefile), all-zero codeword
+        ref = os.path.join(ROOT, "oracle", "_ref", "nb_ref_gf256")
+        ref = ref if os.path.exists(ref) else None
     if ref is None:
         # the built reference binary did not travel: time the restatement (oracle/nbldpc_oracle.c) on the same frames, one core
         nbd = os.path.join(ROOT, "data", "nb")
-        ocode = orc.NBCode(os.path.join(nbd, "BDS.576.288.GF.64.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
-        cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
+        ocode = orc.NBCode(os.path.join(nbd, matrix), os.path.join(nbd, "GF", "Arith.Table.GF.%d.txt" % q))
+        cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32) if q == 64 else np.zeros(ocode.N, np.int32)
         seed = np.array([173, 173, 173], np.int32)
         n = (nframes or 100) * (1 if method == 0 else 3)
-        sigma = orc.nb_sigma(snr, 0.5)
+        sigma = orc.nb_sigma(snr, ocode.rate)
         Lch = [orc.nb_channel(ocode, cw, seed, sigma)[1] for _ in range(n)]
         t0 = time.perf_counter()
         its = 0
@@ -173,15 +178,16 @@ def nb_cpu_baseline(snr, nframes, method=0):
 
 def run_nb(args, rank, world, dev, dist):
     from cuda_ldpc_amd import nbldpc as nb
-    name, _, _, method, frames, snr, iters = WORKLOADS[args.workload]
+    name, q, _, method, frames, snr, iters = WORKLOADS[args.workload]
+    q = q or 64
     if args.frames:
         frames = args.frames
     if args.snr is not None:
         snr = args.snr
     nbd = os.path.join(ROOT, "data", "nb")
-    mul, _, _ = nb.GFInitial(64, os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
+    mul, _, _ = nb.GFInitial(q, os.path.join(nbd, "GF", "Arith.Table.GF.%d.txt" % q))
     code = nb.NBCode(os.path.join(nbd, name), mul)
-    cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
+    cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32) if q == 64 else np.zeros(code.N, np.int32)
     block = min(1024, frames)
     seed = np.array([173, 173, 173], np.int32)
     sigma = nb.sigma_of(snr, code.rate)
@@ -228,8 +234,8 @@ def run_nb(args, rank, world, dev, dist):
         return
     n_all = frames * world * args.steps
     alg_bytes = (4 * code.N * (code.q - 1) + 4 * code.N) * frames  # L_ch in + symbols out
-    kname = {0: "k_nb_ems<64>", 1: "k_nb_tmm<64, false>", 3: "k_nb_tmm<64, true>"}[method]
-    mname = {0: "GF(64) EMS", 1: "GF(64) trellis min-max", 3: "GF(64) layered trellis min-max"}[method]
+    kname = {0: "k_nb_ems<64>" if q == 64 else "k_nb_ems_wide<%d>" % q, 1: "k_nb_tmm<64, false>", 3: "k_nb_tmm<64, true>"}[method]
+    mname = {0: "GF(%d) EMS" % q, 1: "GF(64) trellis min-max", 3: "GF(64) layered trellis min-max"}[method]
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     c = tot.cpu().tolist()
     out = {
@@ -237,7 +243,8 @@ def run_nb(args, rank, world, dev, dist):
         "value": n_all / elapsed, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "myNBLDPC BDS N576_K288 %s batch=%d codewords/GPU Eb/N0=%.1fdB" % ("GF(64) EMS(Nm=2,Nc=2)" if method == 0 else mname, frames, snr),
+        "config": {"workload": "myNBLDPC %s %s batch=%d codewords/GPU Eb/N0=%.1fdB" % ("BDS N576_K288" if q == 64 else name.replace(".txt", ""),
+                                                                                     ("GF(%d) EMS(Nm=2,Nc=2)" % q) if method == 0 else mname, frames, snr),
                    "kernel": "%s one frame per workgroup" % kname, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(kname)[0], "traffic_source": pmc_traffic(kname)[1], "kernel": kname, "kernel_ms": kern_ms,
@@ -247,7 +254,7 @@ def run_nb(args, rank, world, dev, dist):
                   "mean_iterations": c[2] / n_all},
     }
     if world == 1 and not args.no_cpu_baseline:
-        cb = nb_cpu_baseline(snr, args.cpu_frames, method)
+        cb = nb_cpu_baseline(snr, args.cpu_frames, method, q, name)
         if cb:
             out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)
