@@ -36,6 +36,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -154,6 +155,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 {
     constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, G = GM::G;
     constexpr int RPT = GM::RPT, CPT = GM::CPT, MSG = GM::MSG;
+    constexpr bool USE_PRIO = GM::lds_bytes * 2 <= 160 * 1024; // stage priorities matter between the workgroups that share a CU (see k_qc2)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-aware workgroup id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
     // contiguous range of frames so the 4-byte-per-frame rows of y are fetched into one L2 only.
@@ -247,7 +249,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 
     // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
     auto vn_phase = [&](bool (&bad)[NF]) {
-        constexpr int CB = (CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1); // columns with reads in flight together
+        constexpr int CB = (CPT * WV * NF <= 24) ? CPT : ((CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1)); // columns with reads in flight together
         static_for<CPT / CB>([&](auto C0) {
             constexpr int c0 = decltype(C0)::value * CB;
             float R[CB][WV][NF];
@@ -343,34 +345,41 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         if (UNPACKED) lds_ld<NF>(d, lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
         else lds_ld<NF>(d, lds, (int)((pp & 1) ? (saddr[rr][pp / 2] >> 16) : (saddr[rr][pp / 2] & 0xffffu)) * MSG);
     };
-    auto cn_row = [&](auto RR, auto WW) {
-        constexpr int rr = decltype(RR)::value, W = decltype(WW)::value;
-        {
-            float Sv[W][NF];
+    // All of a thread's check rows with W slots each (W <= WC; W < WC only where the rows, hence their weights, are wave-uniform,
+    // i.e. Z is whole waves: J32_L64_Z64 has rows of 5, 6 and 7 edges, paired by weight on the host).  The S values of every row
+    // are requested before the first row's arithmetic: with one workgroup per CU nobody else fills a load's latency.  Slots beyond
+    // a row's own weight read the +inf slot.
+    auto cn_rows = [&](auto WW) {
+        constexpr int W = decltype(WW)::value;
+        float Sv[RPT][W][NF];
 #pragma unroll
-            for (int pp = 0; pp < W; pp++) s_load(Sv[pp], rr, pp);
+        for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+            for (int pp = 0; pp < W; pp++) s_load(Sv[rr][pp], rr, pp);
+        static_for<RPT>([&](auto RR) {
+            constexpr int rr = decltype(RR)::value;
 #pragma unroll
             for (int pp = 0; pp < W; pp++)
 #pragma unroll
-                for (int v = 0; v < NF; v++) Rr[rr][pp][v] = Sv[pp][v] - Rr[rr][pp][v]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
-        }
-        float m2[NF];
-        uint32_t key[NF];
+                for (int v = 0; v < NF; v++) Rr[rr][pp][v] = Sv[rr][pp][v] - Rr[rr][pp][v]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
+            float m2[NF];
+            uint32_t key[NF];
 #pragma unroll
-        for (int v = 0; v < NF; v++) {
-            CnAcc acc;
-            cn_two_smallest<W, NF>(&Rr[rr][0][v], acc.m1, acc.m2, acc.sgn);
-            m2[v] = acc.m2;
-            key[v] = acc.key();
-        }
-        __builtin_amdgcn_s_setprio(QC_PRIO_WR);
-        static_for<W>([&](auto PP) {
-            constexpr int pp = decltype(PP)::value;
+            for (int v = 0; v < NF; v++) {
+                CnAcc acc;
+                cn_two_smallest<W, NF>(&Rr[rr][0][v], acc.m1, acc.m2, acc.sgn);
+                m2[v] = acc.m2;
+                key[v] = acc.key();
+            }
+            if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_WR);
+            static_for<W>([&](auto PP) {
+                constexpr int pp = decltype(PP)::value;
 #pragma unroll
-            for (int v = 0; v < NF; v++) Rr[rr][pp][v] = cn_out(Rr[rr][pp][v], m2[v], key[v]);
-            lds_st_imm<NF, (rr * G * WC + pp) * Z * MSG>(rbase, Rr[rr][pp]);
+                for (int v = 0; v < NF; v++) Rr[rr][pp][v] = cn_out(Rr[rr][pp][v], m2[v], key[v]);
+                lds_st_imm<NF, (rr * G * WC + pp) * Z * MSG>(rbase, Rr[rr][pp]);
+            });
+            if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_CN);
         });
-        __builtin_amdgcn_s_setprio(QC_PRIO_CN);
     };
     for (int it = 1; it < a.max_iter; it++) {
         // keep the 16-bit-packed slot indices packed across iterations (unpacked they cost 2x the VGPRs)
@@ -382,7 +391,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
         bool bad[NF];
 #pragma unroll
         for (int v = 0; v < NF; v++) bad[v] = false;
-        __builtin_amdgcn_s_setprio(QC_PRIO_VN);
+        if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_VN);
         vn_phase(bad);
         if (HIST) flags_publish(bad, it);
 #ifdef QC_STAMPS
@@ -392,25 +401,26 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW
 #ifdef QC_STAMPS
         stamp(__builtin_amdgcn_s_memtime());
 #endif
-        __builtin_amdgcn_s_setprio(QC_PRIO_CN);
+        if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_CN);
         if (HIST) {
             (void)flags_collect(it);
             if (a.per_frame && retire(it)) break;
         }
 
         // CN phase (LDPC_Decoder.cu:279-314)
-        static_for<RPT>([&](auto RR) {
-            constexpr int rr = decltype(RR)::value;
-            constexpr bool ROWU = (Z % 64 == 0) && WC >= 4; // the row, hence its weight, is wave-uniform: a scalar branch picks the exact body
+        {
+            constexpr bool ROWU = (Z % 64 == 0) && WC >= 4; // rows, hence their weights, are wave-uniform: a scalar branch picks the body
             if constexpr (ROWU) {
-                const int wu = __builtin_amdgcn_readfirstlane(wrv[rr]);
-                if (wu <= WC - 2) cn_row(RR, std::integral_constant<int, WC - 2>{});
-                else if (wu == WC - 1) cn_row(RR, std::integral_constant<int, WC - 1>{});
-                else cn_row(RR, std::integral_constant<int, WC>{});
+                int wu = 0;
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) wu = max(wu, __builtin_amdgcn_readfirstlane(wrv[rr]));
+                if (wu <= WC - 2) cn_rows(std::integral_constant<int, WC - 2>{});
+                else if (wu == WC - 1) cn_rows(std::integral_constant<int, WC - 1>{});
+                else cn_rows(std::integral_constant<int, WC>{});
             } else {
-                cn_row(RR, std::integral_constant<int, WC>{});
+                cn_rows(std::integral_constant<int, WC>{});
             }
-        });
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef QC_STAMPS
         if (it == 20 && tid == 0) a.stamps[(size_t)wg * QC_STAMPS + 121] = __builtin_amdgcn_s_memtime(); // wave 0 reaches the CN barrier
@@ -1210,14 +1220,41 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     }
     const bool generic = v.U || v.regstate;
     const int vnw = generic ? 1 : v.WV;
+    // Row variant with wave-uniform rows (Z whole waves) and several rows per thread: the kernel runs ONE body for all of a
+    // thread's rows, sized for the heaviest of them, so that their loads are in flight together.  Which check rows a thread owns is
+    // free (a row is only a name for a set of R slots): hand every thread group rows of equal weight where the weights allow it --
+    // "virtual" row i + rr*G = the (i*RPT + rr)-th row in descending weight order.  The ORDER of a column's edges stays the
+    // reference's, ascending real block row: only the slot a block's messages live in changes.
+    std::vector<int> virt_of(J);
+    for (int j = 0; j < J; j++) virt_of[j] = j;
+    if (!generic && std::string(v.tag) == "row" && Z % 64 == 0 && J / v.G >= 2) {
+        const int G = v.G, RPT = J / G;
+        std::vector<int> order(J);
+        for (int j = 0; j < J; j++) order[j] = j;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rowptr[x + 1] - rowptr[x] > rowptr[y + 1] - rowptr[y]; });
+        for (int k = 0; k < J; k++) virt_of[order[k]] = (k / RPT) + (k % RPT) * G;
+        std::vector<int> real_of(J);
+        for (int j = 0; j < J; j++) real_of[virt_of[j]] = j;
+        std::vector<QcCnEdge> cn2;
+        std::vector<unsigned short> rowptr2(J + 1, 0);
+        for (int vj = 0; vj < J; vj++) {
+            const int j = real_of[vj];
+            for (int e = rowptr[j]; e < rowptr[j + 1]; e++) cn2.push_back(cn[e]);
+            rowptr2[vj + 1] = (unsigned short)cn2.size();
+        }
+        cn = cn2;
+        rowptr = rowptr2;
+    }
     std::vector<QcVnEdge> vn((size_t)L * vnw, QcVnEdge{0, 0});
     std::vector<int> fill(L, 0);
-    for (int j = 0; j < J; j++)
-        for (int e = rowptr[j]; e < rowptr[j + 1]; e++) {
+    for (int j = 0; j < J; j++) { // ascending REAL block row = the reference's edge order
+        const int vj = virt_of[j];
+        for (int e = rowptr[vj]; e < rowptr[vj + 1]; e++) {
             const int l = cn[e].col;
-            // ascending j = the reference's edge order; .e = padded block index row*WC + position
-            if (!generic) vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift};
+            // .e = padded block index (virtual row)*WC + position
+            if (!generic) vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(vj * v.WC + (e - rowptr[vj])), cn[e].shift};
         }
+    }
     std::vector<unsigned char> wvb(L);
     for (int l = 0; l < L; l++) wvb[l] = (unsigned char)wv[l];
     CLDPC_HIP(hipMalloc((void **)&q->d_cn, cn.size() * sizeof(QcCnEdge)), BLDPC_ENOMEM);
