@@ -1,8 +1,9 @@
 """Pin the CPU oracle before anything is compared against it (CPU only).
 
-* binary path: D-hashes / anchor samples that SURVEY.md 8c + Appendix D.3
-  recorded from a host emulation of the reference's kernels (the reference has
-  no buildable CPU path for the binary decoder, so these are its only pins).
+* binary path: PARITY UNPINNED (emulation only).  The D-hashes / anchor samples below are the ones SURVEY.md 8c + Appendix D.3
+  recorded from a host emulation of the reference's kernels built with stand-in CUDA headers in the survey session; the reference
+  has no buildable CPU path for the binary decoder, nothing here can regenerate them, and they cover J4_L24_Z96 and J32_L64_Z64
+  hard bits only (no LLR bits, no other matrix).  tests/test_binary_crosscheck_cpu.py adds a second, independent restatement.
 * NB EMS path: bit-exact against dumps of the REFERENCE's own CPU decoder
   (oracle/_ref/nb_ref built from /root/reference/myNBLDPC/src) committed under
   tests/golden/nb_ref_*.npz, and against the reference fixture codeword
