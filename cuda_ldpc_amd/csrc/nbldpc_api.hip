@@ -30,6 +30,7 @@ struct nbldpc_code {
     int *d_cn_hinv = nullptr, *d_row_order = nullptr, *d_level_begin = nullptr;
     int levels = 0;
     bool tmm_ok = false;
+    int zero_coeff = 0; // an edge with coefficient 0 exists (EMS only, see nbldpc_code_create)
 };
 
 extern "C" const char *nbldpc_last_error(void) { return err_buf(); }
@@ -138,7 +139,8 @@ static NbKernel nb_kernel(int q, int dv)
 static size_t nb_lds_bytes(int N, int M, int q, int dv, int dc)
 {
     return ((size_t)N * dv * nb_pair_stride(q) + (size_t)(q + 1) * M * dc + N + 4) * sizeof(float) + (size_t)q * q +
-           ((size_t)N + 2 * (size_t)N * dv + (size_t)M + 3 * (size_t)M * dc + 2) * sizeof(unsigned short); // graph tables
+           ((size_t)N + 2 * (size_t)N * dv + (size_t)M + 3 * (size_t)M * dc + 2) * sizeof(unsigned short) + // graph tables
+           (size_t)N * dv;                                                                                       // edge-liveness bytes
 }
 
 extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int *vn_w, const int *vn_cn, const int *vn_gf,
@@ -164,7 +166,10 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
             for (int t = 0; t < cn_w[cn]; t++)
                 if (cn_vn[cn * dc + t] == i) { slot = t; break; }
             if (slot < 0) return fail(NBLDPC_EINVAL, "index_in_CN error: VN %d not listed by CN %d", i, cn);
-            if (vn_gf[i * dv + d] <= 0 || vn_gf[i * dv + d] >= q) return fail(NBLDPC_EINVAL, "VN %d edge %d: coefficient %d", i, d, vn_gf[i * dv + d]);
+            // 0 is accepted: the reference reads its exponent-format files (LDPC_N576_K288_GF64_d1_exp.txt) as field elements and
+            // decodes with the zeros in place (such an edge sends nothing and adds nothing to a syndrome); EMS does the same here.
+            // The trellis decoders need the inverse of every coefficient (GFInverse(0) exits in the reference): not offered then.
+            if (vn_gf[i * dv + d] < 0 || vn_gf[i * dv + d] >= q) return fail(NBLDPC_EINVAL, "VN %d edge %d: coefficient %d", i, d, vn_gf[i * dv + d]);
             vn_thr[i * dv + d] = cn * dc + slot;
         }
     for (int r = 0; r < M; r++) {
@@ -202,6 +207,9 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     if (!r) {
         std::vector<int> hinv((size_t)M * dc, 0), level(M, 0), last(N, -1), order(M), lbegin;
         bool inv_ok = true;
+        for (int row = 0; row < M; row++)
+            for (int t = 0; t < cn_w[row]; t++)
+                if (cn_gf[row * dc + t] == 0) { inv_ok = false; c->zero_coeff = 1; } // no inverse (the reference's GFInverse exits)
         for (int i = 0; i < M * dc; i++) {
             const int h = cn_gf[i];
             if (h <= 0) continue;
@@ -267,6 +275,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     a.cn_w = c->d_cn_w; a.cn_src = c->d_cn_src; a.cn_gf = c->d_cn_gf; a.cn_vn = c->d_cn_vn; a.mul = c->d_mul;
     a.N = c->N; a.M = c->M; a.q = c->q; a.dv = c->dv; a.dc = c->dc; a.B = B; a.Nm = Nm; a.Nc = Nc; a.max_iter = maxIT;
     a.dcmax_cfg = maxdc_cfg > 0 ? maxdc_cfg : c->dc;
+    a.zero_coeff = c->zero_coeff;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);

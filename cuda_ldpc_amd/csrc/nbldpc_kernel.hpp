@@ -48,6 +48,7 @@ struct NbArgs {
     const int *cn_vn;  // [M][dc]
     const unsigned char *mul; // [q][q]
     int N, M, q, dv, dc, B, Nm, Nc, max_iter, dcmax_cfg;
+    int zero_coeff; // some edge coefficient is 0 (the reference's exponent-format files): the max arrays need their -inf fill
 };
 
 __host__ __device__ inline int nb_pair_stride(int q) { return 2 * q + 2; } // floats per edge (+2: bank skew)
@@ -254,11 +255,13 @@ template <int D, int NACT> __device__ __forceinline__ void nb_t1(NbCn<NACT> &c, 
 // The float chain through c.s is the critical path of the whole phase (one rounding step after another, as the
 // reference's by-reference recursion dictates); everything else is kept off it: the next batch's pairs and this
 // batch's E entries (their addresses are pure symbol arithmetic) are requested BEFORE the chain runs.
-template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NACT> &c, int symbase)
+template <int D, int NACT, int Q, bool ZS> __device__ __forceinline__ void nb_t0(NbCn<NACT> &c, int symbase)
 {
     if constexpr (D == NACT - 1) {
-        // deepest position with an all-zero prefix: the first q leaves of the walk touch every symbol
-        // exactly once, so they initialise E (no -DBL_MAX fill, LDPC_Decoder.cpp:277-280, needed).
+        // deepest position with an all-zero prefix.  With non-zero coefficients these q leaves touch every symbol exactly once, so
+        // they initialise E (no -DBL_MAX fill, LDPC_Decoder.cpp:277-280, needed) with plain stores.  A code with a coefficient 0 --
+        // the reference's exponent-format files, read as it reads them -- sends all q leaves to ONE symbol: for such codes (ZS,
+        // NbArgs::zero_coeff set by the host) E is filled with -inf at the end of phase B and these leaves are maxima like the others.
         constexpr int CH = (Q % 8 == 0) ? 8 : 1;
         for (int k0 = 0; k0 < Q; k0 += CH) {
             float v[CH];
@@ -272,13 +275,14 @@ template <int D, int NACT, int Q> __device__ __forceinline__ void nb_t0(NbCn<NAC
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 c.s = c.s + v[i];
-                nb_e(c.E, symbase ^ m[i]) = c.s; // the XOR and the add to the base are one v_xad_u32
+                if constexpr (ZS) nb_ds_max(c.E, symbase ^ m[i], c.s);
+                else nb_e(c.E, symbase ^ m[i]) = c.s; // the XOR and the add to the base are one v_xad_u32
                 c.s = c.s - v[i];
             }
         }
     } else {
         c.s = c.s + c.v0[D];
-        nb_t0<D + 1, NACT, Q>(c, symbase ^ c.m0[D]);
+        nb_t0<D + 1, NACT, Q, ZS>(c, symbase ^ c.m0[D]);
         c.s = c.s - c.v0[D];
         int sfx = symbase; // symbol of a leaf that deviates here: every deeper position at k = 0
 #pragma unroll
@@ -358,7 +362,8 @@ __device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, cons
         c.v1[i] = p1.x; c.m1[i] = __float_as_int(p1.y);
     }
     c.s = 0.0f;
-    nb_t0<0, NACT, Q>(c, 0); // ConstructConf(GFQ, 1) :286
+    if (a.zero_coeff) nb_t0<0, NACT, Q, true>(c, 0); // ConstructConf(GFQ, 1) :286 (workgroup-uniform branch)
+    else nb_t0<0, NACT, Q, false>(c, 0);
     c.s = 0.0f;
     int Nc = a.Nc;
     if (a.Nc == a.dcmax_cfg - 1) Nc = W - 1; // :294-297
@@ -391,6 +396,8 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
     unsigned short *t_cn_src = t_cn_w + M;      // [M][dc]
     unsigned short *t_cn_gf = t_cn_src + TC;    // [M][dc]
     unsigned short *t_cn_vn = t_cn_gf + TC;     // [M][dc]
+    unsigned char *t_elive = reinterpret_cast<unsigned char *>(t_cn_vn + TC); // [NE] slot d of a column is an edge when d < its weight
+    for (int i = tid; i < NE; i += NT) t_elive[i] = (i % dv) < a.vn_w[i / dv]; // (a coefficient may be 0: the reference's exponent-format files)
     for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
     for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
     for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
@@ -518,7 +525,7 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
 #pragma unroll
             for (int i = 0; i < SW; i++) {
                 const int edge = e0 + i;
-                live[i] = edge < NE && t_vn_gf[min(edge, NE - 1)] != 0; // unused slots carry coefficient 0, edges never do
+                live[i] = edge < NE && t_elive[min(edge, NE - 1)];
                 const float val = (live[i] && lane < q) ? pairs[edge * PST + 2 * lane] : 0.0f;
                 // order-preserving integer image of the float; +0.0f folds -0 onto +0 (they compare equal)
                 const uint32_t b = __float_as_uint(val + 0.0f);
@@ -564,6 +571,8 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
                 }
             }
         }
+        if (a.zero_coeff) // EMS_L_c2v = -DBL_MAX (:277-280), see nb_t0; nobody reads E between phases A and C
+            for (int i = tid; i < TC * QP; i += NT) E[i] = -__builtin_inff();
         NB_T(2)
         __syncthreads();
         NB_T(4)

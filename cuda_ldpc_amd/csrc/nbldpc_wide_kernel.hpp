@@ -114,8 +114,8 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems_wide(NbA
         // (order-preserving image of the value, q - 1 - position) being pairwise distinct --------------------------------
         for (int r = 0; r < rounds_b; r++) {
             const int edge = r * NG + grp;
-            const bool on_edge = edge < NE && t_vn_gf[edge < NE ? edge : NE - 1] != 0;
             const int ee = edge < NE ? edge : NE - 1;
+            const bool on_edge = edge < NE && (ee % dv) < t_vn_w[ee / dv]; // slot d of a column is an edge when d < its weight
             const float val = pairs[ee * PST + 2 * el];
             const uint32_t b = __float_as_uint(val + 0.0f); // +0.0f folds -0 onto +0 (they compare equal)
             const unsigned long long key = ((unsigned long long)(b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | (unsigned)(q - 1 - el);
@@ -135,6 +135,10 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems_wide(NbA
                 *reinterpret_cast<float2 *>(pairs + ee * PST + 2 * rank) = pr;
             }
             __syncthreads(); // everybody has read its own value and the keys before anything is overwritten / the keys are reused
+        }
+        if (a.zero_coeff) { // EMS_L_c2v = -DBL_MAX (:277-280), see nb_t0; nobody reads E between phases A and C (workgroup-uniform branch)
+            for (int i = tid; i < TC * QP; i += NT) E[i] = -__builtin_inff();
+            __syncthreads();
         }
         // ---- C: check nodes (:272-303), one thread per (row, edge): the walk of nbldpc_kernel.hpp ---------------------
         if (tid < TC) {

@@ -52,7 +52,9 @@ int nbldpc_gf_generate(int q, unsigned primitive_poly, unsigned *TableMultiply, 
 /* Upload a code.  TableMultiply: host unsigned [q][q].  Supported by the fused kernels:
  * q in {16, 32, 64} (a message vector inside one wave, EMS and trellis decoders) and q in {128, 256} (a vector over q/64
  * waves, EMS only: nbldpc_tmm_decode_batch returns NBLDPC_EUNSUPPORTED); row weights 2..6; one frame's message state within
- * one CU's LDS (e.g. BDS.576.288.GF.64.txt, LDPC_N96_K48_GF256_d1_exp.txt); no zero edge coefficients. */
+ * one CU's LDS (e.g. BDS.576.288.GF.64.txt, LDPC_N96_K48_GF256_d1_exp.txt).  A zero edge coefficient is accepted for EMS (the
+ * reference reads its exponent-format files as field elements and decodes with the zeros in place); the trellis decoders refuse
+ * such a code (the reference's GFInverse(0) exits). */
 int nbldpc_code_create(int N, int M, int q, int dvmax, int dcmax, const int *vn_weight, const int *vn_linkCNs,
                        const int *vn_linkCNs_GF, const int *cn_weight, const int *cn_linkVNs, const int *cn_linkVNs_GF,
                        const unsigned *TableMultiply, nbldpc_code **code);

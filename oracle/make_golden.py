@@ -83,6 +83,30 @@ def make_nb(method=0, tag="nb_ref"):
     np.savetxt(os.path.join(ROOT, "data", "nb", "codeword_bds_gf64.txt"), d["cw"][None, :], fmt="%d")
 
 
+def make_nb_exp64():
+    """The reference's exponent-format GF(64) file LDPC_N576_K288_GF64_d1_exp.txt, read the way its Get_H reads it (the exponents as
+    field elements, zeros included), through its own Decoding_EMS (oracle/_ref/nb_ref_exp64, all-zero codeword): 8 frames per Eb/N0."""
+    ref = os.path.join(HERE, "_ref", "nb_ref_exp64")
+    if not os.path.exists(ref):
+        print("oracle/_ref/nb_ref_exp64 missing -> golden not regenerated")
+        return
+    for snr in (3.0, 5.0):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "d.bin")
+            subprocess.check_call([ref, "dump", str(snr), "8", out, "0"], cwd=os.path.join(ROOT, "data", "nb"), stdout=subprocess.DEVNULL)
+            d = parse_nb_dump(out)
+        recs = d["recs"]
+        assert d["q"] == 64 and d["N"] == 96 and d["M"] == 48
+        np.savez_compressed(
+            os.path.join(GOLD, "nb_ref_exp64_%gdB.npz" % snr),
+            snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"],
+            rx=np.stack([r["rx"] for r in recs]), out=np.stack([r["out"] for r in recs]),
+            it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
+            Lch_hash=np.array([orc.fold_hash(r["Lch"]) for r in recs], np.uint32),
+            LLR=np.stack([r["LLR"] for r in recs]), c2v=np.stack([r["c2v"] for r in recs]))
+        print("NB exp64 %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+
+
 def make_nb_gf256():
     """The reference's GF(256) code LDPC_N96_K48_GF256_d1_exp.txt (12 symbols, 6 checks) through its own Decoding_EMS
     (oracle/_ref/nb_ref_gf256: define.h's Matrixfile / GFQ edited at build time, all-zero codeword): 12 frames per Eb/N0."""
@@ -139,3 +163,4 @@ if __name__ == "__main__":
     make_nb(1, "nb_ref_tmm")
     make_nb(3, "nb_ref_ltmm")
     make_nb_gf256()
+    make_nb_exp64()

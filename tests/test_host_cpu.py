@@ -156,14 +156,19 @@ def test_c_program_links_against_the_abi(C, orc, tmp_path):
     assert "mul[2][33]=" in out and "can not open file" in out
 
 
-def test_nb_matrix_with_zero_coefficient_is_rejected(nbm):
-    """LDPC_N576_K288_GF64_d1_exp.txt stores EXPONENTS (0 = alpha^0), which the reference reads as field elements:
-    an edge with coefficient 0 multiplies every symbol to 0 (and codeword_test.h is not a codeword of that file,
-    SURVEY F8).  The library refuses such a graph loudly instead of decoding a degenerate code (validation runs
-    before any device allocation, so this needs no GPU)."""
+def test_nb_matrix_with_out_of_range_coefficient_is_rejected(nbm, tmp_path):
+    """Coefficients outside GF(q) are refused before any device allocation (no GPU needed).  Zero coefficients are NOT: the
+    reference reads its exponent-format files as field elements and decodes with the zeros in place
+    (tests/test_nbldpc_gpu.py::test_exponent_format_matrix_matches_reference_dump)."""
     mul, _, _ = nbm.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
-    with pytest.raises(Exception, match="coefficient 0"):
-        nbm.NBCode(os.path.join(NB, "LDPC_N576_K288_GF64_d1_exp.txt"), mul)
+    src = open(os.path.join(NB, "BDS.576.288.GF.64.txt")).read().split("\n")
+    bad = tmp_path / "bad.txt"
+    toks = src[4].split()
+    toks[1] = "64"  # first edge of the first variable node: coefficient 64 is not an element of GF(64)
+    src[4] = " ".join(toks)
+    bad.write_text("\n".join(src))
+    with pytest.raises(Exception, match="field element|coefficient"):
+        nbm.NBCode(str(bad), mul)
 
 
 def test_division_shortcut_exhaustive(tmp_path):

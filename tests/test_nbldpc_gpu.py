@@ -184,6 +184,25 @@ def test_gf256_ties_and_batch_independence(nb, orc):
     assert np.array_equal(r["iter_number"].view(256, 8)[0].cpu().numpy(), g["it"][:8])
 
 
+@pytest.mark.parametrize("snr", [3, 5])
+def test_exponent_format_matrix_matches_reference_dump(nb, snr):
+    """LDPC_N576_K288_GF64_d1_exp.txt read the way the reference's Get_H reads it (exponents as field elements, two zero
+    coefficients included): EMS against the reference's own decoder built with this Matrixfile; the trellis decoders, which need
+    the inverse of every coefficient (GFInverse(0) exits in the reference), refuse the code."""
+    mul, _, _ = nb.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    code = nb.NBCode(os.path.join(NB, "LDPC_N576_K288_GF64_d1_exp.txt"), mul)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_exp64_%ddB.npz" % snr))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"]))
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+    assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+    assert np.array_equal(r["LLR"].cpu().numpy().view(np.uint32), g["LLR"].view(np.uint32))
+    assert np.array_equal(r["L_c2v"].cpu().numpy().view(np.uint32), g["c2v"].view(np.uint32))
+    with pytest.raises(Exception):
+        nb.Decoding_TMM(code, Lch, int(g["maxit"]))
+
+
 def test_full_size_batch_properties(nb, code, ocode, orc):
     """BASELINE config 5 size (16384 frames): a 32-frame oracle-checked block tiled 512 times; every tile must
     decode identically (frames are independent) and transmitted codewords that decode must be codewords."""

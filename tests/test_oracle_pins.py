@@ -152,6 +152,24 @@ def test_nb_gf256_oracle_bit_exact_vs_reference_dump(orc, snr):
         assert np.array_equal(r["c2v"].view(np.uint32), g["c2v"][fr].view(np.uint32)), "c2v frame %d" % fr
 
 
+@pytest.mark.parametrize("snr", [3, 5])
+def test_nb_exponent_format_matrix_oracle_bit_exact_vs_reference_dump(orc, snr):
+    """LDPC_N576_K288_GF64_d1_exp.txt stores exponents; the reference's Get_H reads them as field elements, two zero coefficients
+    included (Simulation.cpp:347-467), and decodes that code.  The reference built with this Matrixfile (oracle/_ref/nb_ref_exp64,
+    all-zero codeword) against the restatement: channel stream, symbols, iteration counts, flags, final LLR / L_c2v bits."""
+    nbd = os.path.join(DATA, "nb")
+    c = orc.NBCode(os.path.join(nbd, "LDPC_N576_K288_GF64_d1_exp.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
+    g = np.load(os.path.join(GOLDEN, "nb_ref_exp64_%ddB.npz" % snr))
+    seed = np.array([173, 173, 173], np.int32)
+    for fr in range(g["rx"].shape[0]):
+        rx, Lch = orc.nb_channel(c, g["cw"], seed, float(g["sigma"]))
+        assert np.array_equal(rx.view(np.uint32), g["rx"][fr].view(np.uint32)) and orc.fold_hash(Lch) == int(g["Lch_hash"][fr])
+        r = orc.nb_ems_decode(c, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]) and np.array_equal(r["out"], g["out"][fr]), "frame %d" % fr
+        assert np.array_equal(r["LLR"].view(np.uint32), g["LLR"][fr].view(np.uint32))
+        assert np.array_equal(r["c2v"].view(np.uint32), g["c2v"][fr].view(np.uint32))
+
+
 @pytest.mark.parametrize("snr", [2, 3, 5])
 @pytest.mark.parametrize("layered", [False, True])
 def test_nb_tmm_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr, layered):
