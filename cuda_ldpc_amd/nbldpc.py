@@ -145,7 +145,7 @@ def Get_CONSTELLATION(path, n_QAM):
 
 def Demodulate(code, rx, sigma, stream=None, CONSTELLATION=None):
     """Demodulate on the device.  BPSK branch (LDPC_Decoder.cpp:132-157): rx [B, N*m] -> L_ch [B, N, q-1].  With
-    CONSTELLATION (CUDA float32 [q, 2]) the n_QAM != 2 branch (:160-169): rx [B, N, 2] (parity unpinned, include/nbldpc.h)."""
+    CONSTELLATION (CUDA float32 [q, 2]) the n_QAM != 2 branch (:160-169): rx [B, N, 2] (include/nbldpc.h)."""
     if CONSTELLATION is not None:
         if not (rx.is_cuda and rx.dtype == torch.float32 and rx.is_contiguous() and rx.dim() == 3 and tuple(rx.shape[1:]) == (code.N, 2)):
             raise ValueError("rx must be a contiguous CUDA float32 tensor [B, N, 2]")

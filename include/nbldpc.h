@@ -106,9 +106,9 @@ int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *CodeWord_sym, 
  * like B calls of nbldpc_awgn_channel_host. */
 int nbldpc_awgn_channel_device(int seed[3], float sigma, const int *CodeWord_sym, int N, int m, int B, float *rx, void *stream);
 
-/* ---- QAM constellations (n_QAM != 2 branches; n_QAM = q: one constellation point per code symbol).  PARITY UNPINNED: the
- * reference's define.h:25 fixes n_QAM 2, its tree holds no output of these branches and the reference build under oracle/_ref
- * cannot run them; they follow the source text and are checked against the restatement in oracle/nbldpc_oracle.c only. ---- */
+/* ---- QAM constellations (n_QAM != 2 branches; n_QAM = q: one constellation point per code symbol).  The reference's define.h:25
+ * fixes n_QAM 2; these entry points are checked against the reference BUILT with n_QAM 64 and Constellation/GRAY_64QAM.txt
+ * (oracle/_ref/nb_ref_qam64, fixtures tests/golden/nb_ref_qam64_*.npz): channel samples, L_ch and decode results bit for bit. ---- */
 
 /* Replaces Get_CONSTELLATION (src/Simulation.cpp:313-338): n_points records "Point: <idx> Real: <x> Imag: <y>" ->
  * constellation HOST float [n_points][2] (Real, Image), indexed by the record's own idx. */

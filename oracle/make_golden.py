@@ -35,6 +35,7 @@ def parse_nb_dump(path):
     b = open(path, "rb").read()
     hdr = np.frombuffer(b[:32], np.int32)
     N, M, q, dv, dc, maxit, nf, method = (int(x) for x in hdr)
+    nqam, method = method >> 8, method & 0xFF  # n_QAM when it is not 2: one complex channel sample per code symbol
     nv = q - 1 if method == 0 else q  # the trellis decoders keep element 0 in their vectors
     sigma, rate = np.frombuffer(b[32:40], np.float32)
     off = 40
@@ -43,7 +44,8 @@ def parse_nb_dump(path):
     recs = []
     for _fr in range(nf):
         r = {}
-        r["rx"] = np.frombuffer(b[off:off + 4 * N * m], np.float32).copy(); off += 4 * N * m
+        nrx = 2 * N if nqam else N * m
+        r["rx"] = np.frombuffer(b[off:off + 4 * nrx], np.float32).copy(); off += 4 * nrx
         r["Lch"] = np.frombuffer(b[off:off + 4 * N * (q - 1)], np.float32).reshape(N, q - 1).copy(); off += 4 * N * (q - 1)
         r["out"] = np.frombuffer(b[off:off + 4 * N], np.int32).copy(); off += 4 * N
         r["it"], r["ok"] = (int(x) for x in np.frombuffer(b[off:off + 8], np.int32)); off += 8
@@ -107,6 +109,31 @@ def make_nb_exp64():
         print("NB exp64 %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
 
 
+def make_nb_qam64():
+    """The n_QAM != 2 branches of the reference (Modulate / AWGNChannel_CPU / Demodulate, LDPC_Encoder.cpp:18-68,
+    LDPC_Decoder.cpp:160-169) through the reference itself: oracle/_ref/nb_ref_qam64 = define.h with n_QAM 64 and the Gray 64-QAM
+    constellation, BDS code and codeword: 8 frames per Eb/N0 (complex channel samples, L_ch, decode results)."""
+    ref = os.path.join(HERE, "_ref", "nb_ref_qam64")
+    if not os.path.exists(ref):
+        print("oracle/_ref/nb_ref_qam64 missing -> golden not regenerated")
+        return
+    for snr in (11.0, 14.0):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "d.bin")
+            subprocess.check_call([ref, "dump", str(snr), "8", out, "0"], cwd=os.path.join(ROOT, "data", "nb"), stdout=subprocess.DEVNULL)
+            d = parse_nb_dump(out)
+        recs = d["recs"]
+        np.savez_compressed(
+            os.path.join(GOLD, "nb_ref_qam64_%gdB.npz" % snr),
+            snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"],
+            rx=np.stack([r["rx"].reshape(-1, 2) for r in recs]), out=np.stack([r["out"] for r in recs]),
+            it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
+            Lch=np.stack([r["Lch"] for r in recs]),
+            LLR_hash=np.array([orc.fold_hash(r["LLR"]) for r in recs], np.uint32),
+            c2v_hash=np.array([orc.fold_hash(r["c2v"]) for r in recs], np.uint32))
+        print("NB 64-QAM %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+
+
 def make_nb_gf256():
     """The reference's GF(256) code LDPC_N96_K48_GF256_d1_exp.txt (12 symbols, 6 checks) through its own Decoding_EMS
     (oracle/_ref/nb_ref_gf256: define.h's Matrixfile / GFQ edited at build time, all-zero codeword): 12 frames per Eb/N0."""
@@ -164,3 +191,4 @@ if __name__ == "__main__":
     make_nb(3, "nb_ref_ltmm")
     make_nb_gf256()
     make_nb_exp64()
+    make_nb_qam64()

@@ -70,7 +70,8 @@ int main(int argc, char **argv)
             CodeWord_bit[i * H->q_bit + j] = (CodeWord_sym_test[i] & (1 << j)) >> j;
 #endif
     BitToSym(H, CodeWord_sym, CodeWord_bit);
-    Modulate(H, CONSTELLATION, CComplex_sym, CodeWord_bit);
+    /* Modulate indexes the constellation with bits for BPSK and with symbols otherwise (LDPC_Encoder.cpp:18-36) */
+    Modulate(H, CONSTELLATION, CComplex_sym, (n_QAM != 2) ? CodeWord_sym : CodeWord_bit);
 
     AWGN->seed[0] = ix_define;
     AWGN->seed[1] = iy_define;
@@ -86,7 +87,7 @@ int main(int argc, char **argv)
     double secs = 0;
     long iters = 0;
     if (dump) {
-        int hdr[8] = {H->Variablenode_num, H->Checknode_num, GFQ, maxdv, maxdc, maxIT, nframes, method};
+        int hdr[8] = {H->Variablenode_num, H->Checknode_num, GFQ, maxdv, maxdc, maxIT, nframes, method | ((n_QAM != 2 ? n_QAM : 0) << 8)};
         float fh[2] = {AWGN->sigma, H->rate};
         fwrite(hdr, sizeof(int), 8, out);
         fwrite(fh, sizeof(float), 2, out);
@@ -96,7 +97,10 @@ int main(int argc, char **argv)
         AWGNChannel_CPU(H, AWGN, chan, (const CComplex *)CComplex_sym);
         Demodulate(H, AWGN, (const CComplex *)CONSTELLATION, Variablenode, chan);
         if (dump) {
-            for (int b = 0; b < H->bit_length; b++) fwrite(&chan[b].Real, sizeof(float), 1, out);
+            if (n_QAM != 2) /* one complex sample per code symbol (LDPC_Encoder.cpp:45-52) */
+                for (int b = 0; b < H->Variablenode_num; b++) { fwrite(&chan[b].Real, sizeof(float), 1, out); fwrite(&chan[b].Image, sizeof(float), 1, out); }
+            else
+                for (int b = 0; b < H->bit_length; b++) fwrite(&chan[b].Real, sizeof(float), 1, out);
             for (int i = 0; i < H->Variablenode_num; i++) fwrite(Variablenode[i].L_ch, sizeof(float), GFQ - 1, out);
         }
         auto t0 = std::chrono::steady_clock::now();

@@ -515,6 +515,26 @@ def test_qam_demodulate_and_decode_vs_oracle(nb, code, ocode, orc, qam64):
     assert all(int(x) == 1 for x in r["ok"]) and np.array_equal(r["DecodeOutput"].cpu().numpy(), np.tile(cw, (B, 1)))  # 14 dB: all decode
 
 
+@pytest.mark.parametrize("snr", [11, 14])
+def test_qam64_matches_reference_dump(nb, code, orc, qam64, snr):
+    """64-QAM through the reference itself (built with n_QAM 64, tests/golden/nb_ref_qam64_*.npz): the host channel reproduces its
+    complex samples, the device Demodulate its L_ch bits, the decoder its symbols / iteration counts / LLR and c2v hashes."""
+    g = np.load(os.path.join(GOLDEN, "nb_ref_qam64_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    seed = np.array([173, 173, 173], np.int32)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, g["cw"], CONSTELLATION=qam64) for _ in range(g["rx"].shape[0])])
+    assert np.array_equal(rx.view(np.uint32), g["rx"].view(np.uint32))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), sigma, CONSTELLATION=torch.from_numpy(qam64).cuda())
+    assert np.array_equal(Lch.cpu().numpy().view(np.uint32), g["Lch"].view(np.uint32))
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+    assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+    for fr in range(g["rx"].shape[0]):
+        assert orc.fold_hash(r["LLR"][fr].cpu().numpy()) == int(g["LLR_hash"][fr])
+        assert orc.fold_hash(r["L_c2v"][fr].cpu().numpy()) == int(g["c2v_hash"][fr])
+
+
 def test_qam_device_channel_and_simulation_loop(nb, code, ocode, orc, qam64):
     """Device-side QAM channel: same draws as the host loop (seeds equal, samples equal up to the device libm); the simulation
     loop with a constellation stops where a per-frame replay with the oracle stops."""

@@ -170,6 +170,26 @@ def test_nb_exponent_format_matrix_oracle_bit_exact_vs_reference_dump(orc, snr):
         assert np.array_equal(r["c2v"].view(np.uint32), g["c2v"][fr].view(np.uint32))
 
 
+@pytest.mark.parametrize("snr", [11, 14])
+def test_nb_qam64_branches_bit_exact_vs_reference_dump(orc, nbcode, snr):
+    """The n_QAM != 2 branches (Modulate / AWGNChannel_CPU / Demodulate: LDPC_Encoder.cpp:18-68, LDPC_Decoder.cpp:160-169) against the
+    reference itself built with n_QAM 64 and Constellation/GRAY_64QAM.txt (oracle/_ref/nb_ref_qam64): the complex channel samples,
+    L_ch bits and the decode results of 16 frames.  (Round 1 had these branches "parity unpinned".)"""
+    c = nbcode
+    con = orc.nb_read_constellation(os.path.join(NB, "Constellation", "GRAY_64QAM.txt"), 64)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_qam64_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    assert np.float32(orc.nb_sigma(float(g["snr"]), c.rate, 0, 64)) == np.float32(sigma)
+    seed = np.array([173, 173, 173], np.int32)
+    for fr in range(g["rx"].shape[0]):
+        rx, Lch = orc.nb_channel_qam(c, g["cw"], seed, sigma, con)
+        assert np.array_equal(np.asarray(rx).reshape(-1, 2).view(np.uint32), g["rx"][fr].view(np.uint32)), "rx frame %d" % fr
+        assert np.array_equal(Lch.view(np.uint32), g["Lch"][fr].view(np.uint32)), "L_ch frame %d" % fr
+        r = orc.nb_ems_decode(c, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]) and np.array_equal(r["out"], g["out"][fr])
+        assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]) and orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr])
+
+
 @pytest.mark.parametrize("snr", [2, 3, 5])
 @pytest.mark.parametrize("layered", [False, True])
 def test_nb_tmm_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr, layered):
