@@ -134,6 +134,30 @@ def make_nb_qam64():
         print("NB 64-QAM %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
 
 
+def make_nb_gf256_qam256():
+    """GF(256) code over Gray 256-QAM (one point per symbol) through the reference built with GFQ 256, n_QAM 256: 8 frames per Eb/N0."""
+    ref = os.path.join(HERE, "_ref", "nb_ref_gf256_qam256")
+    if not os.path.exists(ref):
+        print("oracle/_ref/nb_ref_gf256_qam256 missing -> golden not regenerated")
+        return
+    for snr in (14.0, 18.0):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "d.bin")
+            subprocess.check_call([ref, "dump", str(snr), "8", out, "0"], cwd=os.path.join(ROOT, "data", "nb"), stdout=subprocess.DEVNULL)
+            d = parse_nb_dump(out)
+        recs = d["recs"]
+        assert d["q"] == 256
+        np.savez_compressed(
+            os.path.join(GOLD, "nb_ref_gf256_qam256_%gdB.npz" % snr),
+            snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"],
+            rx=np.stack([r["rx"].reshape(-1, 2) for r in recs]), out=np.stack([r["out"] for r in recs]),
+            it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
+            Lch=np.stack([r["Lch"] for r in recs]),
+            LLR_hash=np.array([orc.fold_hash(r["LLR"]) for r in recs], np.uint32),
+            c2v_hash=np.array([orc.fold_hash(r["c2v"]) for r in recs], np.uint32))
+        print("NB GF(256) 256-QAM %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+
+
 def make_nb_gf256():
     """The reference's GF(256) code LDPC_N96_K48_GF256_d1_exp.txt (12 symbols, 6 checks) through its own Decoding_EMS
     (oracle/_ref/nb_ref_gf256: define.h's Matrixfile / GFQ edited at build time, all-zero codeword): 12 frames per Eb/N0."""
@@ -192,3 +216,4 @@ if __name__ == "__main__":
     make_nb_gf256()
     make_nb_exp64()
     make_nb_qam64()
+    make_nb_gf256_qam256()

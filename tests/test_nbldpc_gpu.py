@@ -203,6 +203,29 @@ def test_exponent_format_matrix_matches_reference_dump(nb, snr):
         nb.Decoding_TMM(code, Lch, int(g["maxit"]))
 
 
+@pytest.mark.parametrize("snr", [14, 18])
+def test_gf256_qam256_matches_reference_dump(nb, orc, snr):
+    """GF(256) code over Gray 256-QAM (fields and constellations beyond the north star) against the reference built with
+    GFQ 256 / n_QAM 256: host channel samples, device Demodulate L_ch bits, k_nb_ems_wide's symbols / iteration counts / state hashes."""
+    mul, _, _ = nb.GFInitial(256, os.path.join(NB, "GF", "Arith.Table.GF.256.txt"))
+    code = nb.NBCode(os.path.join(NB, "LDPC_N96_K48_GF256_d1_exp.txt"), mul)
+    con = nb.Get_CONSTELLATION(os.path.join(NB, "Constellation", "GRAY_256QAM.txt"), 256)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_gf256_qam256_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    seed = np.array([173, 173, 173], np.int32)
+    rx = np.stack([nb.AWGNChannel_CPU(seed, sigma, code, g["cw"], CONSTELLATION=con) for _ in range(g["rx"].shape[0])])
+    assert np.array_equal(rx.view(np.uint32), g["rx"].view(np.uint32))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), sigma, CONSTELLATION=torch.from_numpy(con).cuda())
+    assert np.array_equal(Lch.cpu().numpy().view(np.uint32), g["Lch"].view(np.uint32))
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+    assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+    for fr in range(g["rx"].shape[0]):
+        assert orc.fold_hash(r["LLR"][fr].cpu().numpy()) == int(g["LLR_hash"][fr])
+        assert orc.fold_hash(r["L_c2v"][fr].cpu().numpy()) == int(g["c2v_hash"][fr])
+
+
 def test_full_size_batch_properties(nb, code, ocode, orc):
     """BASELINE config 5 size (16384 frames): a 32-frame oracle-checked block tiled 512 times; every tile must
     decode identically (frames are independent) and transmitted codewords that decode must be codewords."""

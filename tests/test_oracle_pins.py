@@ -190,6 +190,26 @@ def test_nb_qam64_branches_bit_exact_vs_reference_dump(orc, nbcode, snr):
         assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]) and orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr])
 
 
+@pytest.mark.parametrize("snr", [14, 18])
+def test_nb_gf256_qam256_bit_exact_vs_reference_dump(orc, snr):
+    """GF(256) code over Gray 256-QAM, one point per symbol: the reference built with GFQ 256 / n_QAM 256
+    (oracle/_ref/nb_ref_gf256_qam256, all-zero codeword) against the restatement: channel samples, L_ch, decode results."""
+    nbd = os.path.join(DATA, "nb")
+    c = orc.NBCode(os.path.join(nbd, "LDPC_N96_K48_GF256_d1_exp.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.256.txt"))
+    con = orc.nb_read_constellation(os.path.join(nbd, "Constellation", "GRAY_256QAM.txt"), 256)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_gf256_qam256_%ddB.npz" % snr))
+    sigma = float(g["sigma"])
+    assert np.float32(orc.nb_sigma(float(g["snr"]), c.rate, 0, 256)) == np.float32(sigma)
+    seed = np.array([173, 173, 173], np.int32)
+    for fr in range(g["rx"].shape[0]):
+        rx, Lch = orc.nb_channel_qam(c, g["cw"], seed, sigma, con)
+        assert np.array_equal(np.asarray(rx).reshape(-1, 2).view(np.uint32), g["rx"][fr].view(np.uint32)), "rx frame %d" % fr
+        assert np.array_equal(Lch.view(np.uint32), g["Lch"][fr].view(np.uint32)), "L_ch frame %d" % fr
+        r = orc.nb_ems_decode(c, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]) and np.array_equal(r["out"], g["out"][fr])
+        assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]) and orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr])
+
+
 @pytest.mark.parametrize("snr", [2, 3, 5])
 @pytest.mark.parametrize("layered", [False, True])
 def test_nb_tmm_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr, layered):
