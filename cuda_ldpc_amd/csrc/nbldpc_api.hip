@@ -17,6 +17,7 @@
 #include "nbldpc_kernel.hpp"
 #include "nbldpc_tmm_kernel.hpp"
 #include "nbldpc_wide_kernel.hpp"
+#include "nbldpc_hbm_kernel.hpp"
 
 using namespace cldpc;
 
@@ -31,6 +32,7 @@ struct nbldpc_code {
     int levels = 0;
     bool tmm_ok = false;
     int zero_coeff = 0; // an edge with coefficient 0 exists (EMS only, see nbldpc_code_create)
+    bool hbm = false;   // decoded by k_nb_ems_hbm (state in a global-memory workspace): LDS too small or rows heavier than kNbMaxW
 };
 
 extern "C" const char *nbldpc_last_error(void) { return err_buf(); }
@@ -150,12 +152,14 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     int m = 0;
     while ((1 << m) < q) m++;
     if (N <= 0 || M <= 0 || q < 4 || (1 << m) != q) return fail(NBLDPC_EINVAL, "bad dimensions N=%d M=%d q=%d", N, M, q);
-    if (q != 16 && q != 32 && q != 64 && q != 128 && q != 256)
-        return fail(NBLDPC_EUNSUPPORTED, "fused EMS kernels support q in {16,32,64,128,256} (got %d)", q);
-    if (dv > kNbMaxDv || dc > kNbMaxW) return fail(NBLDPC_EUNSUPPORTED, "dvmax=%d (<= %d) / dcmax=%d (<= %d) unsupported", dv, kNbMaxDv, dc, kNbMaxW);
-    if (M * dc > nb_threads(q) || M > nb_threads(q)) return fail(NBLDPC_EUNSUPPORTED, "M*dcmax = %d exceeds %d check-edge threads per frame", M * dc, nb_threads(q));
-    const size_t lds = q > 64 ? nb_wide_lds_bytes(N, M, q, dv, dc, nb_threads(q)) : nb_lds_bytes(N, M, q, dv, dc);
-    if (lds > 160 * 1024) return fail(NBLDPC_EUNSUPPORTED, "per-frame message state %zu B exceeds the 160 KiB LDS of one CU", lds);
+    if (q > 256) return fail(NBLDPC_EUNSUPPORTED, "EMS kernels support q <= 256 (got %d)", q);
+    if (dv > kNbMaxDv) return fail(NBLDPC_EUNSUPPORTED, "dvmax=%d (<= %d) unsupported", dv, kNbMaxDv);
+    // the fused kernels (state of one frame in LDS, walk unrolled per row weight) when the code fits them, else the workspace kernel
+    const bool fused_q = q == 16 || q == 32 || q == 64 || q == 128 || q == 256;
+    const size_t lds = !fused_q ? 0 : q > 64 ? nb_wide_lds_bytes(N, M, q, dv, dc, nb_threads(q)) : nb_lds_bytes(N, M, q, dv, dc);
+    const bool hbm = !fused_q || dc > kNbMaxW || M * dc > nb_threads(q) || M > nb_threads(q) || lds > 160 * 1024 ||
+                     getenv("NBLDPC_FORCE_HBM") != nullptr; // tests: the workspace kernel on a code the fused kernels take
+    if (hbm && dc > kNbHbmMaxDc) return fail(NBLDPC_EUNSUPPORTED, "dcmax=%d (<= %d) unsupported", dc, kNbHbmMaxDc);
     // cross indices: index_in_CN / index_in_VN (LDPC_Decoder.cpp:106-130), first match
     std::vector<int> vn_thr((size_t)N * dv, 0), cn_src((size_t)M * dc, 0);
     for (int i = 0; i < N; i++)
@@ -192,7 +196,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     }
     nbldpc_code *c = new (std::nothrow) nbldpc_code;
     if (!c) return fail(NBLDPC_ENOMEM, "out of host memory");
-    c->N = N; c->M = M; c->q = q; c->m = m; c->dv = dv; c->dc = dc; c->lds_bytes = lds;
+    c->N = N; c->M = M; c->q = q; c->m = m; c->dv = dv; c->dc = dc; c->lds_bytes = lds; c->hbm = hbm;
     int r = 0;
     if (!r) r = up((void **)&c->d_vn_w, vn_w, (size_t)N * sizeof(int));
     if (!r) r = up((void **)&c->d_vn_thr, vn_thr.data(), vn_thr.size() * sizeof(int));
@@ -233,7 +237,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         for (int i = 0; i < M; i++) lbegin[level[i] + 1]++;
         for (int l = 0; l < levels; l++) lbegin[l + 1] += lbegin[l];
         c->levels = levels;
-        c->tmm_ok = q <= 64 && inv_ok && dc <= kTmmMaxW && levels <= 63 && M <= kTmmThreads && // the trellis kernels keep a vector in one wave
+        c->tmm_ok = (q == 16 || q == 32 || q == 64) && inv_ok && dc <= kTmmMaxW && levels <= 63 && M <= kTmmThreads && // the trellis kernels keep a vector in one wave
                     tmm_lds_bytes(N, M, q, dv, dc, false) <= 160 * 1024;
         if (c->tmm_ok) {
             if (!r) r = up((void **)&c->d_cn_hinv, hinv.data(), hinv.size() * sizeof(int));
@@ -245,7 +249,8 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         hipError_t e = hipSuccess;
         // the attribute belongs to the kernel, not to this code: set it to the CU's whole LDS once and for all, so that
         // creating a second code with a smaller state never lowers the cap under the first one
-        e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hbm) e = hipFuncSetAttribute((const void *)k_nb_ems_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256); // GF(256) table
+        else e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     if (r) { nbldpc_code_destroy(c); return r; }
@@ -277,6 +282,21 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     a.dcmax_cfg = maxdc_cfg > 0 ? maxdc_cfg : c->dc;
     a.zero_coeff = c->zero_coeff;
     hipStream_t st = (hipStream_t)stream;
+    if (c->hbm) {
+        // one workspace slot per workgroup, stream-ordered so that calls on different streams do not share it; at most 2 GiB
+        const size_t slot = nb_hbm_slot_floats(c->N, c->M, c->q, c->dv, c->dc);
+        const size_t cap = std::max<size_t>(1, ((size_t)2 << 30) / (slot * sizeof(float)));
+        const int slots = (int)std::min<size_t>({(size_t)B, (size_t)1024, cap});
+        void *ws = nullptr;
+        CLDPC_HIP(hipMallocAsync(&ws, (size_t)slots * slot * sizeof(float), st), NBLDPC_ENOMEM);
+        a.ws = (float *)ws;
+        a.ws_stride = slot;
+        hipLaunchKernelGGL(k_nb_ems_hbm, dim3(slots), dim3(kNbHbmThreads), (size_t)c->q * c->q, st, a);
+        const hipError_t le = hipGetLastError();
+        CLDPC_HIP(hipFreeAsync(ws, st), NBLDPC_EHIP);
+        CLDPC_HIP(le, NBLDPC_EHIP);
+        return NBLDPC_OK;
+    }
     hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;

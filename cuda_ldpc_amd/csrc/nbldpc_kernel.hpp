@@ -49,6 +49,8 @@ struct NbArgs {
     const unsigned char *mul; // [q][q]
     int N, M, q, dv, dc, B, Nm, Nc, max_iter, dcmax_cfg;
     int zero_coeff; // some edge coefficient is 0 (the reference's exponent-format files): the max arrays need their -inf fill
+    float *ws = nullptr;               // k_nb_ems_hbm only: workspace, one slot per workgroup
+    unsigned long long ws_stride = 0;  // floats per slot
 };
 
 __host__ __device__ inline int nb_pair_stride(int q) { return 2 * q + 2; } // floats per edge (+2: bank skew)

@@ -181,6 +181,34 @@ def make_nb_gf256():
         print("NB GF(256) %.1f dB: iters" % snr, [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
 
 
+def make_nb_heavy_rows():
+    """The reference's two codes whose check rows are heavier than 6: Tanner_74_9_Z128_GF16.txt (GF(16), 9472 symbols, 1152 checks,
+    dv 3, dc 21) and LDPC_N576_K480_GF256_exp.txt (GF(256), 72 symbols, 12 checks, dv 2, dc 12), through the reference's own
+    Decoding_EMS (oracle/_ref/nb_ref_tanner16, nb_ref_gf256_dc12: define.h's Matrixfile / GFQ / maxdc / maxdv edited at build time,
+    all-zero codeword).  The Tanner code costs the reference ~2.4 s per iteration and frame: two frames per Eb/N0."""
+    for tag, q, N, M, cases in (("tanner16", 16, 9472, 1152, ((5.0, 2), (6.0, 2))), ("gf256_dc12", 256, 72, 12, ((5.0, 4), (7.0, 4)))):
+        ref = os.path.join(HERE, "_ref", "nb_ref_" + tag)
+        if not os.path.exists(ref):
+            print("oracle/_ref/nb_ref_%s missing -> golden not regenerated" % tag)
+            continue
+        for snr, frames in cases:
+            with tempfile.TemporaryDirectory() as td:
+                out = os.path.join(td, "d.bin")
+                subprocess.check_call([ref, "dump", str(snr), str(frames), out, "0"], cwd=os.path.join(ROOT, "data", "nb"), stdout=subprocess.DEVNULL)
+                d = parse_nb_dump(out)
+            recs = d["recs"]
+            assert d["q"] == q and d["N"] == N and d["M"] == M
+            np.savez_compressed(
+                os.path.join(GOLD, "nb_ref_%s_%gdB.npz" % (tag, snr)),
+                snr=np.float32(snr), sigma=np.float32(d["sigma"]), rate=np.float32(d["rate"]), maxit=d["maxit"], cw=d["cw"].astype(np.uint8),
+                rx=np.stack([r["rx"] for r in recs]), out=np.stack([r["out"] for r in recs]).astype(np.uint8),
+                it=np.array([r["it"] for r in recs], np.int32), ok=np.array([r["ok"] for r in recs], np.int32),
+                Lch_hash=np.array([orc.fold_hash(r["Lch"]) for r in recs], np.uint32),
+                LLR_hash=np.array([orc.fold_hash(r["LLR"]) for r in recs], np.uint32),
+                c2v_hash=np.array([orc.fold_hash(r["c2v"]) for r in recs], np.uint32))
+            print("NB %s %.1f dB: iters" % (tag, snr), [r["it"] for r in recs], "ok", [r["ok"] for r in recs])
+
+
 # (file, J, L, Z, F, Es/N0 dB, literal table?, hash recorded in SURVEY.md 8c or None)
 BIN_CASES = [
     ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 32, 3.0, False, 0x05A41534),
@@ -217,3 +245,4 @@ if __name__ == "__main__":
     make_nb_exp64()
     make_nb_qam64()
     make_nb_gf256_qam256()
+    make_nb_heavy_rows()

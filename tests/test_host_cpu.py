@@ -187,6 +187,22 @@ def test_division_shortcut_exhaustive(tmp_path):
     assert "checked 4278190078 floats, 0 mismatches" in out, out
 
 
+def test_explicit_stack_walk_equals_the_recursion(tmp_path):
+    """k_nb_ems_hbm walks a check row's configurations with an explicit stack (nb_hbm_conf, any row weight / Nm / Nc); on the host
+    (the function is __host__ __device__) it must leave the same bits in the max array as a plain recursion shaped like the
+    reference's ConstructConf (LDPC_Decoder.cpp:319-359): row weights 1 ... 21, q up to 256 (k reaches 256: not a byte)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "hbm_conf")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "hbm_conf_host_test.hip")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", src, "-o", exe], cwd=str(tmp_path))
+    out = subprocess.check_output([exe], timeout=120).decode()
+    assert out.startswith("OK "), out
+
+
 def test_qam_constellation_and_channel_equal_the_restatement(nbm, orc):
     """n_QAM != 2 branches (PARITY UNPINNED against the reference: its define.h fixes n_QAM = 2 and its tree holds no output of
     these branches): the library's reader and host channel equal the oracle's restatement of Get_CONSTELLATION / Modulate /

@@ -226,6 +226,91 @@ def test_gf256_qam256_matches_reference_dump(nb, orc, snr):
         assert orc.fold_hash(r["L_c2v"][fr].cpu().numpy()) == int(g["c2v_hash"][fr])
 
 
+HEAVY = {"tanner16": ("Tanner_74_9_Z128_GF16.txt", "Arith.Table.GF.16.txt", 16), "gf256_dc12": ("LDPC_N576_K480_GF256_exp.txt", "Arith.Table.GF.256.txt", 256)}
+
+
+@pytest.mark.parametrize("tag,snr", [("tanner16", 5), ("tanner16", 6), ("gf256_dc12", 5), ("gf256_dc12", 7)])
+def test_heavy_row_codes_match_reference_dump(nb, orc, tag, snr):
+    """The reference's codes with check rows heavier than 6 (Tanner_74_9_Z128_GF16.txt: 9472 symbols, row weight 21;
+    LDPC_N576_K480_GF256_exp.txt: GF(256), row weight 12) go through k_nb_ems_hbm (state in a global-memory workspace, the
+    reference's recursion executed as is): symbols, iteration counts (0 ... 20), flags and the L_ch / final LLR / L_c2v bits (hashes)
+    against the reference's own Decoding_EMS built for these files (tests/golden/nb_ref_tanner16_*, nb_ref_gf256_dc12_*)."""
+    mat, tab, q = HEAVY[tag]
+    mul, _, _ = nb.GFInitial(q, os.path.join(NB, "GF", tab))
+    code = nb.NBCode(os.path.join(NB, mat), mul)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%s_%ddB.npz" % (tag, snr)))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"]))
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+    assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"].astype(np.int32))
+    for fr in range(g["rx"].shape[0]):
+        assert orc.fold_hash(Lch[fr].cpu().numpy()) == int(g["Lch_hash"][fr])
+        assert orc.fold_hash(r["LLR"][fr].cpu().numpy()) == int(g["LLR_hash"][fr]), "LLR frame %d" % fr
+        assert orc.fold_hash(r["L_c2v"][fr].cpu().numpy()) == int(g["c2v_hash"][fr]), "c2v frame %d" % fr
+
+
+def test_workspace_kernel_equals_fused_kernels_and_reference(nb, code, orc, monkeypatch):
+    """k_nb_ems_hbm forced (NBLDPC_FORCE_HBM) onto codes the fused kernels take: the BDS GF(64) code against the reference's dumps at
+    three Eb/N0 and against k_nb_ems for other (Nm, Nc) -- the `Nc == maxdc - 1` rule of LDPC_Decoder.cpp:294 included; the
+    exponent-format file with its zero coefficients; ties and signed zeros on the GF(256) row-weight-12 code against the oracle;
+    and a batch larger than the number of workspace slots (a workgroup then decodes several frames, one after the other)."""
+    monkeypatch.setenv("NBLDPC_FORCE_HBM", "1")
+    mul, _, _ = nb.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    forced = nb.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), mul)
+    forced_exp = nb.NBCode(os.path.join(NB, "LDPC_N576_K288_GF64_d1_exp.txt"), mul)
+    monkeypatch.delenv("NBLDPC_FORCE_HBM")
+    for snr in (2, 3, 5):
+        g = np.load(os.path.join(GOLDEN, "nb_ref_%ddB.npz" % snr))
+        Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"]))
+        r = nb.Decoding_EMS(forced, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+        assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+        for fr in range(g["rx"].shape[0]):
+            assert orc.fold_hash(r["LLR"][fr].cpu().numpy()) == int(g["LLR_hash"][fr])
+            assert orc.fold_hash(r["L_c2v"][fr].cpu().numpy()) == int(g["c2v_hash"][fr])
+        for Nm, Nc, maxdc in ((4, 1, 0), (3, 3, 4), (2, 5, 6), (64, 1, 0)):
+            a = nb.Decoding_EMS(code, Lch, Nm, Nc, 6, maxdc=maxdc, want_state=True)
+            b = nb.Decoding_EMS(forced, Lch, Nm, Nc, 6, maxdc=maxdc, want_state=True)
+            torch.cuda.synchronize()
+            for key in ("DecodeOutput", "iter_number", "ok"):
+                assert torch.equal(a[key], b[key]), (Nm, Nc, key)
+            for key in ("LLR", "L_c2v"):
+                assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), (Nm, Nc, key)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_exp64_3dB.npz"))
+    Lch = nb.Demodulate(forced_exp, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"]))
+    r = nb.Decoding_EMS(forced_exp, Lch, 2, 2, int(g["maxit"]), want_state=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+    assert np.array_equal(r["LLR"].cpu().numpy().view(np.uint32), g["LLR"].view(np.uint32))
+    assert np.array_equal(r["L_c2v"].cpu().numpy().view(np.uint32), g["c2v"].view(np.uint32))
+    # ties and signed zeros, GF(256), row weight 12
+    mul256, _, _ = nb.GFInitial(256, os.path.join(NB, "GF", "Arith.Table.GF.256.txt"))
+    c12 = nb.NBCode(os.path.join(NB, "LDPC_N576_K480_GF256_exp.txt"), mul256)
+    o12 = orc.NBCode(os.path.join(NB, "LDPC_N576_K480_GF256_exp.txt"), os.path.join(NB, "GF", "Arith.Table.GF.256.txt"))
+    rng = np.random.default_rng(11)
+    L = rng.integers(-2, 3, size=(3, c12.N, c12.q - 1)).astype(np.float32)
+    L[0, :, ::5] = -0.0
+    L[1] *= 1e30
+    r = nb.Decoding_EMS(c12, torch.from_numpy(L).cuda(), 2, 2, 2, want_state=True)
+    torch.cuda.synchronize()
+    for b in range(3):
+        want = orc.nb_ems_decode(o12, L[b], 2, 2, 2, want_state=True)
+        assert int(r["iter_number"][b]) == want["it"] and int(r["ok"][b]) == want["ok"]
+        assert np.array_equal(r["DecodeOutput"][b].cpu().numpy(), want["out"])
+        assert np.array_equal(r["LLR"][b].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
+        assert np.array_equal(r["L_c2v"][b].cpu().numpy().view(np.uint32), want["c2v"].view(np.uint32))
+    # more frames than workspace slots (1024)
+    g = np.load(os.path.join(GOLDEN, "nb_ref_gf256_dc12_5dB.npz"))
+    Lt = nb.Demodulate(c12, torch.from_numpy(g["rx"]).cuda().repeat(300, 1).contiguous(), float(g["sigma"]))
+    r = nb.Decoding_EMS(c12, Lt, 2, 2, int(g["maxit"]))
+    torch.cuda.synchronize()
+    out = r["DecodeOutput"].view(300, 4, c12.N)
+    assert bool((out == out[:1]).all()) and np.array_equal(out[0].cpu().numpy(), g["out"].astype(np.int32))
+    assert np.array_equal(r["iter_number"].view(300, 4)[7].cpu().numpy(), g["it"])
+
+
 def test_full_size_batch_properties(nb, code, ocode, orc):
     """BASELINE config 5 size (16384 frames): a 32-frame oracle-checked block tiled 512 times; every tile must
     decode identically (frames are independent) and transmitted codewords that decode must be codewords."""

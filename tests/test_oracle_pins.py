@@ -210,6 +210,35 @@ def test_nb_gf256_qam256_bit_exact_vs_reference_dump(orc, snr):
         assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]) and orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr])
 
 
+HEAVY = {"tanner16": ("Tanner_74_9_Z128_GF16.txt", "Arith.Table.GF.16.txt", (9472, 1152, 16, 3, 21)),
+         "gf256_dc12": ("LDPC_N576_K480_GF256_exp.txt", "Arith.Table.GF.256.txt", (72, 12, 256, 2, 12))}
+
+
+@pytest.mark.parametrize("tag,snr", [("tanner16", 5), ("tanner16", 6), ("gf256_dc12", 5), ("gf256_dc12", 7)])
+def test_nb_heavy_row_codes_oracle_bit_exact_vs_reference_dump(orc, tag, snr):
+    """The reference's two codes with check rows heavier than 6 -- Tanner_74_9_Z128_GF16.txt (row weight 21, 9472 symbols) and
+    LDPC_N576_K480_GF256_exp.txt (GF(256), row weight 12) -- through its own Decoding_EMS (oracle/_ref/nb_ref_tanner16,
+    nb_ref_gf256_dc12: define.h's Matrixfile / GFQ / maxdc / maxdv edited at build time, all-zero codeword) against the restatement:
+    channel stream, symbols, iteration counts (0 ... 20), flags, and hashes of the L_ch / final LLR / L_c2v bits."""
+    mat, tab, dims = HEAVY[tag]
+    nbd = os.path.join(DATA, "nb")
+    c = orc.NBCode(os.path.join(nbd, mat), os.path.join(nbd, "GF", tab))
+    assert (c.N, c.M, c.q, c.dv, c.dc) == dims
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%s_%ddB.npz" % (tag, snr)))
+    sigma = float(g["sigma"])
+    assert np.float32(orc.nb_sigma(float(g["snr"]), c.rate)) == np.float32(sigma) and np.float32(c.rate) == np.float32(g["rate"])
+    cw = g["cw"].astype(np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    for fr in range(g["rx"].shape[0]):
+        rx, Lch = orc.nb_channel(c, cw, seed, sigma)
+        assert np.array_equal(rx.view(np.uint32), g["rx"][fr].view(np.uint32)), "rx frame %d" % fr
+        assert orc.fold_hash(Lch) == int(g["Lch_hash"][fr])
+        r = orc.nb_ems_decode(c, Lch, 2, 2, int(g["maxit"]), want_state=True)
+        assert r["it"] == int(g["it"][fr]) and r["ok"] == int(g["ok"][fr]), "frame %d" % fr
+        assert np.array_equal(r["out"], g["out"][fr].astype(np.int32))
+        assert orc.fold_hash(r["LLR"]) == int(g["LLR_hash"][fr]) and orc.fold_hash(r["c2v"]) == int(g["c2v_hash"][fr]), "frame %d" % fr
+
+
 @pytest.mark.parametrize("snr", [2, 3, 5])
 @pytest.mark.parametrize("layered", [False, True])
 def test_nb_tmm_oracle_bit_exact_vs_reference_dump(orc, nbcode, snr, layered):
