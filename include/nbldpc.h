@@ -49,12 +49,14 @@ int nbldpc_gf_load(const char *path, int q, unsigned *TableMultiply, unsigned *T
  * GF/Arith.Table.GF.64.txt); polynomial-basis representation, add == XOR. */
 int nbldpc_gf_generate(int q, unsigned primitive_poly, unsigned *TableMultiply, unsigned *TableAdd, unsigned *TableInverse);
 
-/* Upload a code.  TableMultiply: host unsigned [q][q].  Supported by the fused kernels:
- * q in {16, 32, 64} (a message vector inside one wave, EMS and trellis decoders) and q in {128, 256} (a vector over q/64
- * waves, EMS only: nbldpc_tmm_decode_batch returns NBLDPC_EUNSUPPORTED); row weights 2..6; one frame's message state within
- * one CU's LDS (e.g. BDS.576.288.GF.64.txt, LDPC_N96_K48_GF256_d1_exp.txt).  A zero edge coefficient is accepted for EMS (the
- * reference reads its exponent-format files as field elements and decodes with the zeros in place); the trellis decoders refuse
- * such a code (the reference's GFInverse(0) exits). */
+/* Upload a code.  TableMultiply: host unsigned [q][q].  q a power of two, 4 <= q <= 256; column weights <= 8; row weights 2..64.
+ * The fused kernels (one frame's message state inside one CU's LDS) take q in {16, 32, 64} (a message vector inside one wave, EMS
+ * and trellis decoders) and q in {128, 256} (a vector over q/64 waves, EMS only) with row weights up to 6 (e.g.
+ * BDS.576.288.GF.64.txt, LDPC_N96_K48_GF256_d1_exp.txt); every other code (Tanner_74_9_Z128_GF16.txt: row weight 21, 7.5 MB of
+ * state; LDPC_N576_K480_GF256_exp.txt: row weight 12) is decoded by the workspace kernel (EMS only, same results, far slower).
+ * nbldpc_tmm_decode_batch returns NBLDPC_EUNSUPPORTED where the trellis kernels do not apply.  A zero edge coefficient is
+ * accepted for EMS (the reference reads its exponent-format files as field elements and decodes with the zeros in place); the
+ * trellis decoders refuse such a code (the reference's GFInverse(0) exits). */
 int nbldpc_code_create(int N, int M, int q, int dvmax, int dcmax, const int *vn_weight, const int *vn_linkCNs,
                        const int *vn_linkCNs_GF, const int *cn_weight, const int *cn_linkVNs, const int *cn_linkVNs_GF,
                        const unsigned *TableMultiply, nbldpc_code **code);
