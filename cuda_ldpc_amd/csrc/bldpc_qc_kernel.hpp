@@ -1014,6 +1014,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
 }
 
 #include "bldpc_qcr_kernel.hpp" // k_qcr: check states in registers, S in LDS (long blocks)
+#include "bldpc_qcr2_kernel.hpp" // k_qcr2: the same with hardware-addressed (M0 + lane) LDS accesses
 
 // AND of all frames' flag histories -> first iteration at which every frame's flag is set.
 __global__ __launch_bounds__(256) void k_hist_and(const unsigned long long *hist, int F, unsigned long long *out)
@@ -1066,6 +1067,9 @@ inline const QcVariant *qc_variants(int *count)
 #define XR(J, L, Z, TPB, WCS, MINW, YB)                                                                     \
     {1, J, L, Z, WCS, 31, 0, MINW, TPB, 0, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, false>,               \
      k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1},
+#define XR2(J, L, Z, TPB, WCS, YB)                                                                          \
+    {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, false>,                        \
+     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, true>, "regstate-m0", 0, 0, 2},
     static const QcVariant v[] = {
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
@@ -1089,6 +1093,8 @@ inline const QcVariant *qc_variants(int *count)
         XC(384, 384, 2, 32, 24) /* Z = 384: L <=  64 */
         XC(640, 640, 1, 40, 24) /* Z = 640: L <=  40 */
         XC(1024, 1024, 1, 32, 24) /* Z = 1024: L <= 32 */
+        /* check states in registers, S with halos in LDS, hardware-addressed accesses (bldpc_qcr2_kernel.hpp) */
+        XR2(15, 30, 1280, 768, 8, 10) /* J15_L30_Z1280 (BASELINE config 4): 157.5 KB */
         /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp): long blocks with 4 N <= LDS */
         XR(15, 30, 1280, 768, 8, 7, 10) /* J15_L30_Z1280 (BASELINE config 4): 12 waves, 8 of them cover 2 tiles of Z (5 tiles per SIMD) */
     };
@@ -1096,6 +1102,7 @@ inline const QcVariant *qc_variants(int *count)
 #undef X2
 #undef XC
 #undef XR
+#undef XR2
     *count = (int)(sizeof(v) / sizeof(v[0]));
     return v;
 }
@@ -1161,11 +1168,32 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     int nvar = 0;
     const QcVariant *vars = qc_variants(&nvar);
     const char *pin = getenv("BLDPC_QC_VARIANT");
+    // k_qcr2 gives per-lane addresses to two slots per (block row, tile): no more than two of a row's blocks may wrap past Z in
+    // the same tile of 64 circulant positions (shifts taken relative to the register-resident column, as the kernel sees them)
+    auto qcr2_fits = [&]() -> bool {
+        int lc = -1;
+        for (int l = 0; l < L && lc < 0; l++)
+            if (wv[l] == J) lc = l;
+        if (lc < 0 || Z % 64 != 0) return false;
+        for (int j = 0; j < J; j++) {
+            int rot = 0;
+            for (int e = rowptr[j]; e < rowptr[j + 1]; e++)
+                if (cn[e].col == lc) rot = cn[e].shift;
+            for (int t = 0; t < Z / 64; t++) {
+                int nw = 0;
+                for (int e = rowptr[j]; e < rowptr[j + 1]; e++)
+                    if (cn[e].col != lc && (64 * t + (cn[e].shift - rot + Z) % Z) % Z > Z - 64) nw++;
+                if (nw > 2) return false;
+            }
+        }
+        return true;
+    };
     for (int vi = 0; vi < nvar && q->variant < 0; vi++) {
         const QcVariant &v = vars[vi];
         if (pin && atoi(pin) != vi) continue;
         if (v.regstate) { // register-state kernel
-            const size_t lds = (size_t)L * Z * 4 + 16;
+            if (v.regstate == 2 && !qcr2_fits()) continue; // three blocks of one row wrap in the same tile: k_qcr takes the code
+            const size_t lds = v.regstate == 2 ? (size_t)L * (Z + 64) * 4 + 272 : (size_t)L * Z * 4 + 16;
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.MINW > Wcmin || L > 255 || Z > 2047 || lds > kLdsBytes) continue;
             q->lds_bytes = (int)lds;
         } else if (v.U) { // compressed-state kernel: geometry-generic
@@ -1204,8 +1232,48 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
             }
         }
         q->lc = lc;
-        CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
-        CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+        if (v.regstate == 2) { // k_qcr2: per (block row, tile, slot) the byte offset of the wave's 64 rotated positions, and the flags
+            const int NT = Z / 64, ZH = Z + 64, WCS = v.WC;
+            const unsigned inf_base = (unsigned)(L * ZH * 4); // 64 words of +inf: what a padding slot addresses
+            std::vector<unsigned> ta((size_t)J * NT * WCS, inf_base), tx((size_t)J * NT * WCS, inf_base);
+            bool fits = true;
+            for (int j = 0; j < J && fits; j++)
+                for (int t = 0; t < NT && fits; t++) {
+                    // slots of this (block row, tile): the blocks whose 64 positions wrap past Z go last (slots WCS-2, WCS-1 take
+                    // per-lane addresses in phase 2), the others first, padding in between
+                    std::vector<std::pair<int, int>> plain, wrapped; // (column, rb)
+                    for (int p = 1; p < WCS; p++) {
+                        const unsigned m = cm[(size_t)j * WCS + p];
+                        if ((m >> 21) & 1u) continue;
+                        const int col = (int)(m & 255u), rb = (64 * t + (int)((m >> 8) & 2047u)) % Z;
+                        (rb > Z - 64 ? wrapped : plain).push_back({col, rb});
+                    }
+                    if (wrapped.size() > 2) { fits = false; break; }
+                    unsigned *a1 = &ta[((size_t)j * NT + t) * WCS], *a2 = &tx[((size_t)j * NT + t) * WCS];
+                    unsigned c0 = 64u | (64u << 8);
+                    int slot = 1;
+                    for (auto &b : plain) {
+                        a1[slot] = a2[slot] = (unsigned)((b.first * ZH + b.second) * 4);
+                        slot++;
+                    }
+                    for (size_t k = 0; k < wrapped.size(); k++) {
+                        const int gs = WCS - 1 - (int)k; // >= slot: a row has at most WCS - 1 blocks here
+                        a1[gs] = a2[gs] = (unsigned)((wrapped[k].first * ZH + wrapped[k].second) * 4);
+                        const unsigned kw = (unsigned)(Z - wrapped[k].second); // lanes from Z - rb on wrap
+                        c0 = gs == WCS - 2 ? ((c0 & ~127u) | kw) : ((c0 & ~(127u << 8)) | (kw << 8));
+                    }
+                    a2[0] = c0;
+                }
+            if (!fits) { q->variant = -1; return BLDPC_OK; } // (the selection loop has checked: cannot happen)
+            if (L * ZH > 65535) { q->variant = -1; return BLDPC_OK; }
+            CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, ta.size() * sizeof(unsigned)), BLDPC_ENOMEM);
+            CLDPC_HIP(hipMalloc((void **)&q->d_vn_meta, tx.size() * sizeof(unsigned)), BLDPC_ENOMEM);
+            CLDPC_HIP(hipMemcpy(q->d_cn_meta, ta.data(), ta.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+            CLDPC_HIP(hipMemcpy(q->d_vn_meta, tx.data(), tx.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+        } else {
+            CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);
+            CLDPC_HIP(hipMemcpy(q->d_cn_meta, cm.data(), cm.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+        }
     }
     if (v.U) { // meta tables of the compressed-state kernel
         const int WVS = (Wv + 1) / 2 * 2; // column edge lists padded to whole rounds of 2 with entries of the zero state (row J)
