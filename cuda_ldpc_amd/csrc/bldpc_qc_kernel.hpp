@@ -1069,7 +1069,7 @@ inline const QcVariant *qc_variants(int *count)
      k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1},
 #define XR2(J, L, Z, TPB, WCS, YB)                                                                          \
     {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, false>,                        \
-     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, true>, "regstate-m0", 0, 0, 2},
+     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, true>, "regstate-halo", 0, 0, 2},
     static const QcVariant v[] = {
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
