@@ -1067,9 +1067,9 @@ inline const QcVariant *qc_variants(int *count)
 #define XR(J, L, Z, TPB, WCS, MINW, YB)                                                                     \
     {1, J, L, Z, WCS, 31, 0, MINW, TPB, 0, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, false>,               \
      k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1},
-#define XR2(J, L, Z, TPB, WCS, YB)                                                                          \
-    {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, false>,                        \
-     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB>, true>, "regstate-halo", 0, 0, 2},
+#define XR2(J, L, Z, TPB, WCS, YB, NG) /* CPT carries NG here */                                              \
+    {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, false>,                    \
+     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true>, "regstate-halo", 0, NG, 2},
     static const QcVariant v[] = {
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
@@ -1094,7 +1094,8 @@ inline const QcVariant *qc_variants(int *count)
         XC(640, 640, 1, 40, 24) /* Z = 640: L <=  40 */
         XC(1024, 1024, 1, 32, 24) /* Z = 1024: L <= 32 */
         /* check states in registers, S with halos in LDS, hardware-addressed accesses (bldpc_qcr2_kernel.hpp) */
-        XR2(15, 30, 1280, 768, 8, 10) /* J15_L30_Z1280 (BASELINE config 4): 157.5 KB */
+        XR2(15, 30, 1280, 768, 8, 10, 2) /* J15_L30_Z1280 (BASELINE config 4): 157.5 KB; at most 2 wrapped blocks per (row, tile) */
+        XR2(15, 30, 1280, 768, 8, 10, 3) /* the same shape with other shifts: at most 3 */
         /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp): long blocks with 4 N <= LDS */
         XR(15, 30, 1280, 768, 8, 7, 10) /* J15_L30_Z1280 (BASELINE config 4): 12 waves, 8 of them cover 2 tiles of Z (5 tiles per SIMD) */
     };
@@ -1170,7 +1171,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     const char *pin = getenv("BLDPC_QC_VARIANT");
     // k_qcr2 gives per-lane addresses to two slots per (block row, tile): no more than two of a row's blocks may wrap past Z in
     // the same tile of 64 circulant positions (shifts taken relative to the register-resident column, as the kernel sees them)
-    auto qcr2_fits = [&]() -> bool {
+    auto qcr2_fits = [&](int ng) -> bool {
         int lc = -1;
         for (int l = 0; l < L && lc < 0; l++)
             if (wv[l] == J) lc = l;
@@ -1183,7 +1184,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
                 int nw = 0;
                 for (int e = rowptr[j]; e < rowptr[j + 1]; e++)
                     if (cn[e].col != lc && (64 * t + (cn[e].shift - rot + Z) % Z) % Z > Z - 64) nw++;
-                if (nw > 2) return false;
+                if (nw > ng) return false;
             }
         }
         return true;
@@ -1192,7 +1193,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         const QcVariant &v = vars[vi];
         if (pin && atoi(pin) != vi) continue;
         if (v.regstate) { // register-state kernel
-            if (v.regstate == 2 && !qcr2_fits()) continue; // three blocks of one row wrap in the same tile: k_qcr takes the code
+            if (v.regstate == 2 && (!qcr2_fits(v.CPT) || getenv("BLDPC_NO_HALO"))) continue; // three blocks of one row wrap in the same tile: k_qcr takes the code (env: tests)
             const size_t lds = v.regstate == 2 ? (size_t)L * (Z + 64) * 4 + 272 : (size_t)L * Z * 4 + 16;
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.MINW > Wcmin || L > 255 || Z > 2047 || lds > kLdsBytes) continue;
             q->lds_bytes = (int)lds;
@@ -1248,9 +1249,9 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
                         const int col = (int)(m & 255u), rb = (64 * t + (int)((m >> 8) & 2047u)) % Z;
                         (rb > Z - 64 ? wrapped : plain).push_back({col, rb});
                     }
-                    if (wrapped.size() > 2) { fits = false; break; }
+                    if ((int)wrapped.size() > v.CPT) { fits = false; break; }
                     unsigned *a1 = &ta[((size_t)j * NT + t) * WCS], *a2 = &tx[((size_t)j * NT + t) * WCS];
-                    unsigned c0 = 64u | (64u << 8);
+                    unsigned c0 = 0x40404040u;
                     int slot = 1;
                     for (auto &b : plain) {
                         a1[slot] = a2[slot] = (unsigned)((b.first * ZH + b.second) * 4);
@@ -1260,7 +1261,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
                         const int gs = WCS - 1 - (int)k; // >= slot: a row has at most WCS - 1 blocks here
                         a1[gs] = a2[gs] = (unsigned)((wrapped[k].first * ZH + wrapped[k].second) * 4);
                         const unsigned kw = (unsigned)(Z - wrapped[k].second); // lanes from Z - rb on wrap
-                        c0 = gs == WCS - 2 ? ((c0 & ~127u) | kw) : ((c0 & ~(127u << 8)) | (kw << 8));
+                        c0 = (c0 & ~(127u << (8 * k))) | (kw << (8 * k));
                     }
                     a2[0] = c0;
                 }

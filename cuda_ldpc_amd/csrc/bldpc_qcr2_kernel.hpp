@@ -12,8 +12,9 @@
 // tile of every block wraps (its 64 positions straddle Z: 5 % of the (block, tile) pairs); the order of a row's slots is free
 // (min1 / min2 / sign product are symmetric, a variable is met once per block row), so the host orders the slots PER
 // (block row, tile) and puts the wrapped block, if any, into one of the last two slots, whose addresses take three more
-// instructions (lanes from k on lie 4 Z bytes lower, k = 64 when nothing wraps).  A matrix with three wrapped blocks in
-// one (row, tile) -- J15_L30_Z1280 has at most two -- keeps to k_qcr (the host checks).  The halos are refreshed once per
+// instructions (lanes from k on lie 4 Z bytes lower, k = 64 when nothing wraps).  J15_L30_Z1280 has at most two wrapped
+// blocks per (row, tile); random shifts of the same shape exceed two in two matrices out of three and three in one out of
+// sixteen: NG = 2 and NG = 3 are both instantiated, the host picks the first that fits and k_qcr beyond.  The halos are refreshed once per
 // iteration, by the closing pass that adds the channel values, before phase 1 reads through them.  The code stays
 // straight-line and short: the loop body is 75 KB of instructions streamed through a 64 KB cache every iteration; a first
 // version with a wave-uniform branch per wrapped block into out-of-line code lost 20 % to it, and even the never-executed
@@ -34,8 +35,9 @@
 #define QCR2_ABLATE 0 // experiments only (timing, wrong results): 1 no zeroing pass, 2 nor its barrier, 4 no wrapped blocks, 8 no phase 2, 16 no phase 1
 #endif
 
-template <int J_, int L_, int Z_, int TPB_, int WCS_, int YB_> struct Qcr2Geom {
+template <int J_, int L_, int Z_, int TPB_, int WCS_, int YB_, int NG_> struct Qcr2Geom {
     static constexpr int J = J_, L = L_, Z = Z_, TPB = TPB_, WCS = WCS_, ZR = (Z + TPB - 1) / TPB, YB = YB_;
+    static constexpr int NG = NG_;           // slots with per-lane addresses in phase 2 (the last NG of a row): wrapped blocks per (row, tile) it takes
     static constexpr int NT = Z / 64;        // tiles of the circulant
     static constexpr int ZH = Z + 64;        // words per column of S, halo included
     static constexpr int S_BYTES = L * ZH * 4;
@@ -43,7 +45,7 @@ template <int J_, int L_, int Z_, int TPB_, int WCS_, int YB_> struct Qcr2Geom {
     static constexpr bool RAGGED = (Z % TPB) != 0;
     static_assert((L * Z) % (TPB * YB) == 0, "the closing pass runs in whole batches");
     static_assert(Z % 64 == 0 && TPB % 64 == 0 && TPB <= 1024, "threads must tile the circulant in whole waves");
-    static_assert(WCS >= 3 && WCS <= 27, "sign bits and the 5-bit index share one word; slot 0 is the register-resident column");
+    static_assert(NG >= 1 && NG <= 4 && WCS > NG && WCS <= 27, "sign bits and the 5-bit index share one word; slot 0 is the register-resident column");
     static_assert(lds_bytes <= 160 * 1024, "S with its halos must fit one CU's LDS");
 };
 
@@ -177,15 +179,15 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
             }
 #pragma unroll
             for (int z = 0; z < NZ; z++) {
-                // slot 0's word: first wrapped lane of the two general slots (64: none)
-                const unsigned c0 = (QCR2_ABLATE & 4) ? 0x4040u : tc[z][0];
+                // slot 0's word: first wrapped lane of each per-lane slot (64: none), slot WCS-1-g in bits 8g .. 8g+6
+                const unsigned c0 = (QCR2_ABLATE & 4) ? 0x40404040u : tc[z][0];
                 int va[WCS];
                 float prev[WCS];
 #pragma unroll
                 for (int p = 1; p < WCS; p++) {
                     va[p] = (int)tc[z][p] + la;
-                    if (p == WCS - 2) va[p] -= (lane >= (int)(c0 & 127u)) ? 4 * Z : 0;        // the row's wrapped block for this tile,
-                    if (p == WCS - 1) va[p] -= (lane >= (int)((c0 >> 8) & 127u)) ? 4 * Z : 0; // if any, sits in one of the last two slots
+                    if (p >= WCS - GM::NG) // the row's wrapped blocks for this tile, if any, sit in the last NG slots: lanes from k on lie 4 Z lower
+                        va[p] -= (lane >= (int)((c0 >> (8 * (WCS - 1 - p))) & 127u)) ? 4 * Z : 0;
                     float sv[1];
                     lds_ld<1>(sv, lds, va[p]);
                     prev[p] = sv[0];

@@ -536,6 +536,49 @@ def test_other_lifting_sizes_random_matrices(C, orc, tmp_path, Z, J, L):
     assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_long_block_kernels_on_random_shifts(C, orc, tmp_path, monkeypatch, seed):
+    """J15_L30_Z1280's block pattern with RANDOM shifts: k_qcr2 (halo columns, tabulated wave-linear offsets, the wrapped blocks of a
+    (row, tile) in the last two or three, per-lane, slots; seed 3 needs the three-slot instantiation) must meet every wrap position,
+    and a matrix with more wrapped blocks in one (row, tile) must fall back to k_qcr; both kernels against the oracle (a-posteriori bits, hard decisions, flags, history and
+    per-frame exits) and against each other on the same code."""
+    J, L, Z = 15, 30, 1280
+    base = np.loadtxt(os.path.join(BL, "J15_L30_Z1280_BlockH.txt"), dtype=np.int64).reshape(J, L)
+    rng = np.random.default_rng(seed)
+    H = np.where(base >= 0, rng.integers(0, Z, size=(J, L)), -1)
+    if seed % 2 == 0:  # a row's shifts a few positions past the same tile boundary: all of its blocks wrap in the same tile
+        H = np.where(base >= 0, (64 * rng.integers(0, Z // 64, size=(J, 1)) + rng.integers(1, 6, size=(J, L))) % Z, -1)
+        lc = int(np.argmax((base >= 0).sum(0) == J))
+        H[:, lc] = np.where(base[:, lc] >= 0, 0, -1)  # (the kernels see shifts relative to this column)
+    path = str(tmp_path / "H.txt")
+    with open(path, "w") as f:
+        for j in range(J):
+            f.write("\t".join(str(int(x)) for x in H[j]) + "\r\n")
+    F = 3
+    y = _channel(orc, L * Z, F, 0.2)
+    ocode = orc.BinaryCode(path, J, L, Z)
+    code = C.BinaryCode.from_blockh(path, J, L, Z)
+    want = orc.bldpc_decode(ocode, y, F, 6, early_exit=0, want_app=True)
+    got = _decode(C, code, y, F, max_iter=6, exit_mode=C.EXIT_FIXED, want_app=True)
+    assert ("regstate-halo" in code.last_kernel) == (seed % 2 == 1), code.last_kernel
+    assert "regstate" in code.last_kernel
+    _assert_same(got, want, code.N, F)
+    want = orc.bldpc_decode(ocode, y, F, 25, early_exit=1, want_app=True)
+    got = _decode(C, code, y, F, max_iter=25, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
+    _assert_same(got, want, code.N, F)
+    Dw, appw, itw = _oracle_per_frame(orc, ocode, y, F, 25)
+    D, app, it, _ = _decode_per_frame(C, code, y, F, 25, C.KERNEL_QC_LDS)
+    assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
+    if seed % 2 == 1:  # the same code pinned to k_qcr
+        monkeypatch.setenv("BLDPC_NO_HALO", "1")
+        old = C.BinaryCode.from_blockh(path, J, L, Z)
+        monkeypatch.delenv("BLDPC_NO_HALO")
+        want = orc.bldpc_decode(ocode, y, F, 6, early_exit=0, want_app=True)
+        got = _decode(C, old, y, F, max_iter=6, exit_mode=C.EXIT_FIXED, want_app=True)
+        assert "regstate<" in old.last_kernel, old.last_kernel
+        _assert_same(got, want, code.N, F)
+
+
 # ---- per-frame termination (bldpc_decode_per_frame): the reference rule on batches of one frame -------------------------
 def _oracle_per_frame(orc, ocode, y, F, max_iter):
     """LDPC_Decoder.cu:94-156 run on every frame alone (Num_Frames_OneTime = 1): D column, flag, iteraTime, sums per frame."""
