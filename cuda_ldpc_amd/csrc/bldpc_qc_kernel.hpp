@@ -1078,6 +1078,7 @@ inline const QcVariant *qc_variants(int *count)
         QC_VARIANTS(X)
         /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp), several workgroups per CU */
         XR(12, 69, 256, 256, 23, 22, 3) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22): 69 KB, 2 WG/CU */
+        XR2(4, 24, 512, 512, 20, 8, 5)   /* J4_L24_Z512: 55 KB, 2 WG/CU; at most 5 wrapped blocks per (row, tile) */
         XR(4, 24, 512, 512, 20, 20, 8)  /* J4_L24_Z512: 48 KB, 3 WG/CU                                                      */
         /* compressed check state (bldpc_qcc_kernel.hpp): any J, L with ceil(L/G) <= CPT and row weight <= WCS */
         XC(256, 256, 4, 18, 24) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22)       */
@@ -1240,8 +1241,8 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
             bool fits = true;
             for (int j = 0; j < J && fits; j++)
                 for (int t = 0; t < NT && fits; t++) {
-                    // slots of this (block row, tile): the blocks whose 64 positions wrap past Z go last (slots WCS-2, WCS-1 take
-                    // per-lane addresses in phase 2), the others first, padding in between
+                    // slots of this (block row, tile): the blocks whose 64 positions wrap past Z go last (the last NG slots take
+                    // per-lane addresses in phase 2), the others first, padding in between (plain + wrapped <= WCS - 1: no overlap)
                     std::vector<std::pair<int, int>> plain, wrapped; // (column, rb)
                     for (int p = 1; p < WCS; p++) {
                         const unsigned m = cm[(size_t)j * WCS + p];
@@ -1251,19 +1252,18 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
                     }
                     if ((int)wrapped.size() > v.CPT) { fits = false; break; }
                     unsigned *a1 = &ta[((size_t)j * NT + t) * WCS], *a2 = &tx[((size_t)j * NT + t) * WCS];
-                    unsigned c0 = 0x40404040u;
                     int slot = 1;
                     for (auto &b : plain) {
                         a1[slot] = a2[slot] = (unsigned)((b.first * ZH + b.second) * 4);
                         slot++;
                     }
+                    for (int g = 0; g < v.CPT; g++) // the per-lane slots, whatever they hold: offset | first wrapped lane << 18 (64: no lane wraps)
+                        a2[WCS - 1 - g] = (a2[WCS - 1 - g] & 0x3ffffu) | (64u << 18);
                     for (size_t k = 0; k < wrapped.size(); k++) {
-                        const int gs = WCS - 1 - (int)k; // >= slot: a row has at most WCS - 1 blocks here
-                        a1[gs] = a2[gs] = (unsigned)((wrapped[k].first * ZH + wrapped[k].second) * 4);
-                        const unsigned kw = (unsigned)(Z - wrapped[k].second); // lanes from Z - rb on wrap
-                        c0 = (c0 & ~(127u << (8 * k))) | (kw << (8 * k));
+                        const int gs = WCS - 1 - (int)k;
+                        a1[gs] = (unsigned)((wrapped[k].first * ZH + wrapped[k].second) * 4);
+                        a2[gs] = a1[gs] | ((unsigned)(Z - wrapped[k].second) << 18); // lanes from Z - rb on wrap
                     }
-                    a2[0] = c0;
                 }
             if (!fits) { q->variant = -1; return BLDPC_OK; } // (the selection loop has checked: cannot happen)
             if (L * ZH > 65535) { q->variant = -1; return BLDPC_OK; }

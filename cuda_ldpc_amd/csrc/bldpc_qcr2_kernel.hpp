@@ -45,7 +45,7 @@ template <int J_, int L_, int Z_, int TPB_, int WCS_, int YB_, int NG_> struct Q
     static constexpr bool RAGGED = (Z % TPB) != 0;
     static_assert((L * Z) % (TPB * YB) == 0, "the closing pass runs in whole batches");
     static_assert(Z % 64 == 0 && TPB % 64 == 0 && TPB <= 1024, "threads must tile the circulant in whole waves");
-    static_assert(NG >= 1 && NG <= 4 && WCS > NG && WCS <= 27, "sign bits and the 5-bit index share one word; slot 0 is the register-resident column");
+    static_assert(NG >= 1 && WCS > NG && WCS <= 27 && S_BYTES < (1 << 18), "sign bits and the 5-bit index share one word; slot 0 is the register-resident column");
     static_assert(lds_bytes <= 160 * 1024, "S with its halos must fit one CU's LDS");
 };
 
@@ -58,7 +58,7 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const qcr_const_u32 *ta = (const qcr_const_u32 *)a.cn_meta; // [J][NT][WCS] byte offset of lane 0's word for every (block row, tile, slot)
-    const qcr_const_u32 *tx = (const qcr_const_u32 *)a.vn_meta; // [J][NT][WCS]: phase-2 offsets (slot 0: first wrapped lanes of the two general slots)
+    const qcr_const_u32 *tx = (const qcr_const_u32 *)a.vn_meta; // [J][NT][WCS]: phase-2 offsets; the last NG slots carry their first wrapped lane in bits 18..24
     const int lcbase = a.lc * Z;
     auto y_at = [&](int stride_idx) -> float { // y[tid + stride_idx * TPB]
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, tid * 4, stride_idx * TPB * 4, 0));
@@ -179,15 +179,16 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
             }
 #pragma unroll
             for (int z = 0; z < NZ; z++) {
-                // slot 0's word: first wrapped lane of each per-lane slot (64: none), slot WCS-1-g in bits 8g .. 8g+6
-                const unsigned c0 = (QCR2_ABLATE & 4) ? 0x40404040u : tc[z][0];
                 int va[WCS];
                 float prev[WCS];
 #pragma unroll
                 for (int p = 1; p < WCS; p++) {
-                    va[p] = (int)tc[z][p] + la;
-                    if (p >= WCS - GM::NG) // the row's wrapped blocks for this tile, if any, sit in the last NG slots: lanes from k on lie 4 Z lower
-                        va[p] -= (lane >= (int)((c0 >> (8 * (WCS - 1 - p))) & 127u)) ? 4 * Z : 0;
+                    if (p >= WCS - GM::NG) { // the row's wrapped blocks for this tile, if any, sit in the last NG slots: lanes from k on
+                        const unsigned w = (QCR2_ABLATE & 4) ? (tc[z][p] & 0x3ffffu) | (64u << 18) : tc[z][p]; // lie 4 Z lower (k in bits 18..24, 64: none)
+                        va[p] = (int)(w & 0x3ffffu) + la - ((lane >= (int)(w >> 18)) ? 4 * Z : 0);
+                    } else {
+                        va[p] = (int)tc[z][p] + la;
+                    }
                     float sv[1];
                     lds_ld<1>(sv, lds, va[p]);
                     prev[p] = sv[0];
