@@ -314,10 +314,8 @@ def main():
     import ctypes
     from cuda_ldpc_amd._lib import check, lib
 
-    def step():
-        r = C.LDPC_Decoder_GPU(code, y, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
-        check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, frames, 0, r["iteraTime"],
-                                  ctypes.c_void_p(SIM._dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream)), "Statistic")
+    def step():  # LDPC_Decoder_GPU + Statistic, the pair of calls of the reference's Simulation_GPU loop (Simulation.cu:143-145)
+        C.Decode_Statistic(code, y, SIM._dev, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
 
     def barrier():
         if world > 1:
@@ -333,10 +331,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
-        r = C.LDPC_Decoder_GPU(code, y, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
+        C.Decode_Statistic(code, y, SIM._dev, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
         ev[k][1].record(stream)
-        check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, frames, 0, r["iteraTime"],
-                                  ctypes.c_void_p(SIM._dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream)), "Statistic")
         if k == args.steps - 1:
             dom_ms_last = code.last_kernel_ms()  # dominant kernel alone (events recorded inside bldpc_decode)
     counters = SIM._dev.clone()
@@ -374,7 +370,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(code.last_kernel)[0], "traffic_source": pmc_traffic(code.last_kernel)[1],
                          "kernel": code.last_kernel, "kernel_ms": kern_ms, "decode_call_ms": call_ms,
-                         "achieved_decode_call": alg_bytes / (call_ms * 1e-3) / 1e9,  # regroup + decode + unpack: the kernels that move the algorithmic bytes
+                         "achieved_decode_call": alg_bytes / (call_ms * 1e-3) / 1e9,  # the whole bldpc_decode_statistic call: (regroup +) decode + unpack with the error counts + the counters
                          "algorithmic_bytes_per_launch": alg_bytes, "model": model, "onchip": pmc_onchip(code.last_kernel, kern_ms)},
             "stats": {"frames": frames * world * args.steps, "error_frames": c[0], "error_bits": c[1],
                       "FER": c[0] / (frames * world * args.steps), "BER": c[1] / (frames * world * args.steps) / code.K},

@@ -7,8 +7,8 @@ torch.distributed.  There is no CPU fallback: importing the decoders without
 the built extension raises.
 """
 from . import _lib  # noqa: F401
-from .bldpc import (BinaryCode, Get_H, Transform_H, LDPC_Decoder_GPU, Statistic, SimCounters, AWGNChannel_CPU, AWGNChannel_GPU, sigma_of,  # noqa: F401
+from .bldpc import (BinaryCode, Get_H, Transform_H, LDPC_Decoder_GPU, Decode_Statistic, Statistic, SimCounters, AWGNChannel_CPU, AWGNChannel_GPU, sigma_of,  # noqa: F401
                     EXIT_FIXED, EXIT_BATCH_GLOBAL, EXIT_PER_FRAME, KERNEL_AUTO, KERNEL_TABLE, KERNEL_QC_LDS)
 
-__all__ = ["BinaryCode", "Get_H", "Transform_H", "LDPC_Decoder_GPU", "Statistic", "SimCounters", "AWGNChannel_CPU", "AWGNChannel_GPU", "sigma_of",
+__all__ = ["BinaryCode", "Get_H", "Transform_H", "LDPC_Decoder_GPU", "Decode_Statistic", "Statistic", "SimCounters", "AWGNChannel_CPU", "AWGNChannel_GPU", "sigma_of",
            "EXIT_FIXED", "EXIT_BATCH_GLOBAL", "EXIT_PER_FRAME", "KERNEL_AUTO", "KERNEL_TABLE", "KERNEL_QC_LDS"]

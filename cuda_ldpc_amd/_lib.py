@@ -37,6 +37,7 @@ lib.bldpc_decode.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i
 lib.bldpc_decode_per_frame.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
 lib.bldpc_statistic.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
 lib.bldpc_statistic_per_frame.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]
+lib.bldpc_decode_statistic.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
 lib.bldpc_set_profiling.argtypes = [c_void_p, c_int]
 lib.bldpc_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_float)]
 lib.bldpc_awgn_channel_host.argtypes = [c_void_p, ctypes.c_float, c_void_p, c_void_p, c_int, c_int]

@@ -169,6 +169,27 @@ def LDPC_Decoder_GPU(code, Channel_Out, max_iter=50, length=0, exit_mode=EXIT_BA
     return dict(D=D, iteraTime=it.value, app=app, flag_hist=hist)
 
 
+def Decode_Statistic(code, Channel_Out, counters, max_iter=50, length=0, exit_mode=EXIT_BATCH_GLOBAL, kernel=KERNEL_AUTO, D=None, stream=None):
+    """LDPC_Decoder_GPU followed by Statistic against the all-zero codeword, the pair of calls of Simulation_GPU's loop
+    (Simulation.cu:143-145), as ONE call of the C ABI (bldpc_decode_statistic): same D, same iteration counts, same counters
+    (device int64[5], accumulated); with a single-launch exit mode the errors are counted while D is written.
+    Returns dict(D, iteraTime or None, iters or None)."""
+    if not (Channel_Out.is_cuda and Channel_Out.dtype == torch.float32 and Channel_Out.is_contiguous()):
+        raise ValueError("Channel_Out must be a contiguous CUDA float32 tensor")
+    if Channel_Out.dim() != 2 or Channel_Out.shape[0] != code.N:
+        raise ValueError("Channel_Out must be [N=%d, F]" % code.N)
+    F = int(Channel_Out.shape[1])
+    dev = Channel_Out.device
+    if D is None:
+        D = torch.empty((code.N + 1, F), dtype=torch.int32, device=dev)
+    iters = torch.empty(F, dtype=torch.int32, device=dev) if exit_mode == EXIT_PER_FRAME else None
+    it = ctypes.c_int(0)
+    st = ctypes.c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
+    check(lib.bldpc_decode_statistic(code._h, _dev_ptr(Channel_Out), F, max_iter, length, exit_mode, kernel, _dev_ptr(D), _dev_ptr(iters),
+                                     _dev_ptr(counters), ctypes.byref(it), st), "Decode_Statistic")
+    return dict(D=D, iteraTime=None if iters is not None else it.value, iters=iters)
+
+
 @dataclass
 class SimCounters:
     """The counters of struct Simulation (struct.cuh:17-33)."""

@@ -386,6 +386,41 @@ static int statistic_impl(const bldpc_code *cc, const int *D, const int *cw, int
     return BLDPC_OK;
 }
 
+// bldpc_decode (or bldpc_decode_per_frame when iters != NULL) followed by bldpc_statistic against the all-zero codeword, as
+// Simulation_GPU calls them back to back (Simulation.cu:143-145): same D, same counters.  On the fused kernels with a single
+// launch (FIXED and PER_FRAME exits) the error counts come out of the pass that unpacks the hard bits into D, and the second
+// pass over D's 4 N F bytes is not made.
+extern "C" int bldpc_decode_statistic(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int kernel, int *D,
+                                      int *iters, long long *counters, int *itera, void *stream)
+{
+    if (!c || !counters || !itera) return fail(BLDPC_EINVAL, "bldpc_decode_statistic: null argument");
+    if ((exit_mode == BLDPC_EXIT_PER_FRAME) != (iters != nullptr))
+        return fail(BLDPC_EINVAL, "bldpc_decode_statistic: iters goes with the per-frame exit and with nothing else");
+    if (F <= 0) return fail(BLDPC_EINVAL, "bldpc_decode_statistic: F=%d must be positive", F);
+    const int slen = length == 0 ? c->K : length;
+    hipStream_t st = (hipStream_t)stream;
+    const bool single = exit_mode == BLDPC_EXIT_FIXED || exit_mode == BLDPC_EXIT_PER_FRAME;
+    if (single && c->has_qc && slen >= 0 && slen <= c->N) {
+        if ((size_t)F * sizeof(int) > c->errs.cap) {
+            CLDPC_HIP(c->errs.reserve((size_t)F * sizeof(int)), BLDPC_ENOMEM);
+            CLDPC_HIP(hipMemsetAsync(c->errs.p, 0, (size_t)F * sizeof(int), st), BLDPC_EHIP);
+        }
+        c->qc.stat_errs = (int *)c->errs.p;
+        c->qc.stat_length = slen;
+    }
+    c->qc.stat_done = false;
+    const int r = decode_impl(c, y, F, max_iter, length, exit_mode, kernel, D, nullptr, nullptr, itera, iters, stream);
+    const bool fused = c->qc.stat_done;
+    c->qc.stat_errs = nullptr;
+    c->qc.stat_done = false;
+    if (r) return r;
+    if (!fused) return statistic_impl(c, D, nullptr, F, length, *itera, iters, counters, stream);
+    hipLaunchKernelGGL(k_stat_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, (int *)c->errs.p, D + (size_t)c->N * F, F, *itera,
+                       iters, counters);
+    CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
+    return BLDPC_OK;
+}
+
 extern "C" int bldpc_statistic(const bldpc_code *cc, const int *D, const int *cw, int F, int length, int itera, long long *counters,
                                void *stream)
 {

@@ -804,7 +804,9 @@ template <int NF> __global__ __launch_bounds__(256) void k_regroup_y(const float
 
 // Unpack the hard bits into the reference's D layout (int32 [N][F], frame-fastest): one thread per
 // (word w, 4 frames); reads 4 words, writes 32 rows of int4 -- stores coalesce along the frame dimension.
-__global__ __launch_bounds__(256) void k_expand_bits(const unsigned *bits, int *D, int F, int NW)
+// errs != nullptr: the message-bit errors of Statistic against the all-zero codeword (Simulation.cu:249-257) are counted here, from
+// the packed words -- the ones among bits 0 .. length-1 of a frame -- instead of by a second pass over the 4 N F bytes of D.
+__global__ __launch_bounds__(256) void k_expand_bits(const unsigned *bits, int *D, int F, int NW, int *errs, int length)
 {
     const int f = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int w = blockIdx.y;
@@ -812,6 +814,15 @@ __global__ __launch_bounds__(256) void k_expand_bits(const unsigned *bits, int *
     unsigned x[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = (f + i < F) ? bits[(size_t)(f + i) * NW + w] : 0u;
+    if (errs) {
+        const int lo = w * 32;
+        const unsigned mask = lo + 32 <= length ? ~0u : (lo < length ? (1u << (length - lo)) - 1u : 0u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = __builtin_popcount(x[i] & mask);
+            if (c) atomicAdd(&errs[f + i], c); // (x[i] = 0 beyond F)
+        }
+    }
     int *row = D + (size_t)w * 32 * F + f;
     if (f + 3 < F && (F & 3) == 0) {
 #pragma unroll
@@ -1128,6 +1139,10 @@ struct QcPlan {
     char name[96] = "qc_lds(unavailable)";
     mutable int ran_to_max = 0; // BATCH_GLOBAL: the previous batch did not stop before max_iter (a performance hint, never a result)
     mutable bool y_in_place = false; // this decode call hands the kernels the caller's [N][F] array itself (qc_decode)
+    // bldpc_decode_statistic: per-frame error counts wanted from the pass that unpacks the hard bits (single-launch modes only)
+    mutable int *stat_errs = nullptr;
+    mutable int stat_length = 0;
+    mutable bool stat_done = false;
 };
 
 inline void qc_plan_release(QcPlan *q)
@@ -1391,7 +1406,11 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     const int NW = q->L * q->Z / 32;
-    if (expand) hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW);
+    if (expand) {
+        hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW, q->stat_errs,
+                           q->stat_length);
+        if (q->stat_errs) q->stat_done = true;
+    }
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
 }

@@ -10,9 +10,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .bldpc import (EXIT_BATCH_GLOBAL, KERNEL_AUTO, AWGNChannel_CPU, AWGNChannel_GPU, LDPC_Decoder_GPU, SimCounters, sigma_of)
-from ._lib import check, lib
-import ctypes
+from .bldpc import (EXIT_BATCH_GLOBAL, KERNEL_AUTO, AWGNChannel_CPU, AWGNChannel_GPU, Decode_Statistic, SimCounters, sigma_of)
 
 
 def Simulation_GPU(code, seed, sigma, SIM, Num_Frames_OneTime=4096, maxIT=50, exit_mode=EXIT_BATCH_GLOBAL, kernel=KERNEL_AUTO,
@@ -42,15 +40,7 @@ def Simulation_GPU(code, seed, sigma, SIM, Num_Frames_OneTime=4096, maxIT=50, ex
         seed[:] = sharding.lcg_jump(seed, F * per_frame)
         dev_cnt.zero_()
         if count:
-            r = LDPC_Decoder_GPU(code, yd, max_iter=maxIT, length=length, exit_mode=exit_mode, kernel=kernel, D=D)
-            st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            if r["iteraTime"] is None:  # EXIT_PER_FRAME: one iteration count per frame
-                check(lib.bldpc_statistic_per_frame(code._h, ctypes.c_void_p(D.data_ptr()), None, count, length,
-                                                    ctypes.c_void_p(r["iters"].data_ptr()), ctypes.c_void_p(dev_cnt.data_ptr()), st),
-                      "Statistic")
-            else:
-                check(lib.bldpc_statistic(code._h, ctypes.c_void_p(D.data_ptr()), None, count, length, r["iteraTime"],
-                                          ctypes.c_void_p(dev_cnt.data_ptr()), st), "Statistic")
+            Decode_Statistic(code, yd, dev_cnt, max_iter=maxIT, length=length, exit_mode=exit_mode, kernel=kernel, D=D)  # Simulation.cu:143-145
         sharding.allreduce_counters(dev_cnt, dist)
         c = dev_cnt.cpu().tolist()
         SIM.num_Error_Frames += c[0]

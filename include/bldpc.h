@@ -136,6 +136,14 @@ int bldpc_statistic(const bldpc_code *code, const int *D, const int *CodeWord, i
 int bldpc_statistic_per_frame(const bldpc_code *code, const int *D, const int *CodeWord, int F, int length, const int *iters,
                               long long *counters, void *stream);
 
+/* bldpc_decode (iters == NULL; FIXED or BATCH_GLOBAL exit) or bldpc_decode_per_frame (iters != NULL, exit_mode PER_FRAME)
+ * followed by bldpc_statistic / bldpc_statistic_per_frame against the all-zero codeword, the pair of calls of the
+ * reference's Simulation_GPU loop (Simulation.cu:143-145): D, *iteraTime / iters and the accumulated counters are the same
+ * as from the two calls.  With the fused kernels and a single launch (FIXED, PER_FRAME) the message-bit errors are counted
+ * from the packed hard bits while D is written, which saves the statistics pass over D. */
+int bldpc_decode_statistic(bldpc_code *code, const float *Channel_Out, int F, int max_iter, int length, int exit_mode, int kernel,
+                           int *D, int *iters, long long *counters, int *iteraTime, void *stream);
+
 /* Host input generator, bit-identical to the reference's (the "identical AWGN inputs" of the parity
  * contract): AWGNChannel_CPU + RandomModule (LDPC_Encoder.cu:25-56).  seed[3] is advanced in place
  * (AWGNChannel.seed, struct.cuh:13), sigma as main.cu:120-127 computes it (bldpc_sigma below).

@@ -579,6 +579,39 @@ def test_long_block_kernels_on_random_shifts(C, orc, tmp_path, monkeypatch, seed
         _assert_same(got, want, code.N, F)
 
 
+@pytest.mark.parametrize("J,L,Z,snr,F", [(4, 24, 96, 2.2, 70), (4, 24, 96, 2.2, 37), (32, 64, 64, -0.8, 18), (15, 30, 1280, -0.4, 5)])
+def test_decode_statistic_equals_the_two_calls(C, orc, J, L, Z, snr, F):
+    """bldpc_decode_statistic = LDPC_Decoder_GPU + Statistic (Simulation.cu:143-145) in one call: D, iteration counts and the five
+    counters must equal those of the two calls in every exit mode, on the fused kernels (errors counted from the packed hard bits:
+    whole and partial words of `length`, even and odd batch sizes) and on the table kernels (plain sequence), accumulated over
+    two batches."""
+    import ctypes
+    from cuda_ldpc_amd._lib import check, lib
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    y = torch.from_numpy(np.ascontiguousarray(_channel(orc, L * Z, F, snr)).reshape(L * Z, F)).cuda()
+    for kern in (C.KERNEL_AUTO, C.KERNEL_TABLE):
+        for mode in (C.EXIT_FIXED, C.EXIT_PER_FRAME, C.EXIT_BATCH_GLOBAL):
+            for length in (0, 100, code.N, 1):
+                a = torch.zeros(5, dtype=torch.int64, device="cuda")
+                b = torch.zeros(5, dtype=torch.int64, device="cuda")
+                for _ in range(2):
+                    r = C.LDPC_Decoder_GPU(code, y, max_iter=9, length=length, exit_mode=mode, kernel=kern)
+                    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    if mode == C.EXIT_PER_FRAME:
+                        check(lib.bldpc_statistic_per_frame(code._h, ctypes.c_void_p(r["D"].data_ptr()), None, F, length,
+                                                            ctypes.c_void_p(r["iters"].data_ptr()), ctypes.c_void_p(a.data_ptr()), st), "Statistic")
+                    else:
+                        check(lib.bldpc_statistic(code._h, ctypes.c_void_p(r["D"].data_ptr()), None, F, length, r["iteraTime"],
+                                                  ctypes.c_void_p(a.data_ptr()), st), "Statistic")
+                    q = C.Decode_Statistic(code, y, b, max_iter=9, length=length, exit_mode=mode, kernel=kern)
+                    torch.cuda.synchronize()
+                    assert torch.equal(q["D"], r["D"]) and q["iteraTime"] == r["iteraTime"]
+                    if mode == C.EXIT_PER_FRAME:
+                        assert torch.equal(q["iters"], r["iters"])
+                assert torch.equal(a, b), (kern, mode, length, a.tolist(), b.tolist())
+                assert int(a[1]) > 0 or length in (1, 100)  # the batch does hold bit errors
+
+
 # ---- per-frame termination (bldpc_decode_per_frame): the reference rule on batches of one frame -------------------------
 def _oracle_per_frame(orc, ocode, y, F, max_iter):
     """LDPC_Decoder.cu:94-156 run on every frame alone (Num_Frames_OneTime = 1): D column, flag, iteraTime, sums per frame."""
