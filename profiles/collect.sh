@@ -9,7 +9,7 @@ tag=$1; name=$2; match=$3; shift 3
 out=gpurun_out/${tag}_${name}
 export TMPDIR=/tmp
 python bench.py "$@" > ${out}_bench.json 2> ${out}_bench.err
-rocprofv3 --kernel-trace --stats -d ${out}_trace -o run -- python bench.py "$@" --no-cpu-baseline --steps 5 --warmup 1 > ${out}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d ${out}_trace -o run -- python bench.py "$@" --no-cpu-baseline --steps 20 --warmup 2 > ${out}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d ${out}_fetch -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d ${out}_write -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d ${out}_sq -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_sq.log 2>&1
