@@ -1282,9 +1282,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
                 }
             if (!fits) { q->variant = -1; return BLDPC_OK; } // (the selection loop has checked: cannot happen)
             if (L * ZH * 4 + 272 >= (1 << 18)) { q->variant = -1; return BLDPC_OK; } // offsets are 18-bit fields
-            CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, ta.size() * sizeof(unsigned)), BLDPC_ENOMEM);
-            CLDPC_HIP(hipMalloc((void **)&q->d_vn_meta, tx.size() * sizeof(unsigned)), BLDPC_ENOMEM);
-            CLDPC_HIP(hipMemcpy(q->d_cn_meta, ta.data(), ta.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
+            CLDPC_HIP(hipMalloc((void **)&q->d_vn_meta, tx.size() * sizeof(unsigned)), BLDPC_ENOMEM); // one table for both phases (ta = tx without the lane tags)
             CLDPC_HIP(hipMemcpy(q->d_vn_meta, tx.data(), tx.size() * sizeof(unsigned), hipMemcpyHostToDevice), BLDPC_EHIP);
         } else {
             CLDPC_HIP(hipMalloc((void **)&q->d_cn_meta, cm.size() * sizeof(unsigned)), BLDPC_ENOMEM);

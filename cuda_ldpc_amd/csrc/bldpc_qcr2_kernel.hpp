@@ -57,8 +57,10 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
     constexpr int J = GM::J, Z = GM::Z, TPB = GM::TPB, WCS = GM::WCS, N = GM::L * Z, NS = N / TPB, YB = GM::YB, NT = GM::NT, ZH = GM::ZH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const qcr_const_u32 *ta = (const qcr_const_u32 *)a.cn_meta; // [J][NT][WCS] byte offset of lane 0's word for every (block row, tile, slot)
-    const qcr_const_u32 *tx = (const qcr_const_u32 *)a.vn_meta; // [J][NT][WCS]: phase-2 offsets; the last NG slots carry their first wrapped lane in bits 18..24
+    // [J][NT][WCS]: byte offset of lane 0's word for every (block row, tile, slot), ONE table for both phases (9.6 KB for J15_L30_Z1280: it
+    // has to stay in the 16 KB scalar cache -- two tables of this size did not, and every block row then waited for an L2 round trip:
+    // 5.07 -> 4.5x ms); the last NG slots carry their first wrapped lane in bits 18..24, which phase 1 (reads through the halo) masks off
+    const qcr_const_u32 *tx = (const qcr_const_u32 *)a.vn_meta;
     const int lcbase = a.lc * Z;
     auto y_at = [&](int stride_idx) -> float { // y[tid + stride_idx * TPB]
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, tid * 4, stride_idx * TPB * 4, 0));
@@ -91,14 +93,14 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
     for (int it = 1; it < a.max_iter; it++) {
         // fresh (opaque) table pointers per phase, see k_qcr; the lane offset too: left alone the compiler forms `la + constant` for
         // every column and stride of the closing pass ahead of the loop and keeps 30 registers of them
-        asm volatile("" : "+s"(ta), "+v"(la));
+        asm volatile("" : "+s"(tx), "+v"(la));
         // ---- phase 1: check nodes on S of iteration `it` (LDPC_Decoder.cu:279-314).  The offsets of block row j + 1 are
         // requested while row j is computed: the tables (29 KB) do not stay in the scalar cache, a load costs an L2 round trip.
         unsigned tn[NZ][WCS];
 #pragma unroll
         for (int z = 0; z < NZ; z++)
 #pragma unroll
-            for (int p = 1; p < WCS; p++) tn[z][p] = ta[(0 * NT + wv + z * (TPB / 64)) * WCS + p];
+            for (int p = 1; p < WCS; p++) tn[z][p] = tx[(0 * NT + wv + z * (TPB / 64)) * WCS + p];
 #pragma unroll
         for (int j = 0; j < ((QCR2_ABLATE & 16) ? 0 : J); j++) {
             float Sv[NZ][WCS];
@@ -108,7 +110,7 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
 #pragma unroll
                 for (int p = 1; p < WCS; p++) {
                     float sv[1];
-                    lds_ld<1>(sv, lds, (int)tn[z][p] + la);
+                    lds_ld<1>(sv, lds, (int)(p >= WCS - GM::NG ? tn[z][p] & 0x3ffffu : tn[z][p]) + la); // (a per-lane slot's word carries its wrap lane: phase 2)
                     Sv[z][p] = sv[0];
                 }
             }
@@ -116,7 +118,7 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
 #pragma unroll
                 for (int z = 0; z < NZ; z++)
 #pragma unroll
-                    for (int p = 1; p < WCS; p++) tn[z][p] = ta[((j + 1) * NT + wv + z * (TPB / 64)) * WCS + p];
+                    for (int p = 1; p < WCS; p++) tn[z][p] = tx[((j + 1) * NT + wv + z * (TPB / 64)) * WCS + p];
             }
 #pragma unroll
             for (int z = 0; z < NZ; z++) {
