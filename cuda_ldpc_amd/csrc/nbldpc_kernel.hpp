@@ -49,6 +49,7 @@ struct NbArgs {
     const unsigned char *mul; // [q][q]
     int N, M, q, dv, dc, B, Nm, Nc, max_iter, dcmax_cfg;
     int zero_coeff; // some edge coefficient is 0 (the reference's exponent-format files): the max arrays need their -inf fill
+    int *work = nullptr;               // k_nb_ems: != nullptr: persistent workgroups take frame after frame from this counter (zeroed by the host)
     float *ws = nullptr;               // k_nb_ems_hbm only: workspace, one slot per workgroup
     unsigned long long ws_stride = 0;  // floats per slot
 };
@@ -376,7 +377,7 @@ __device__ void nb_cn_update(const NbArgs &a, const unsigned short *cn_src, cons
 template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems(NbArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int frame = blockIdx.x;
+    int frame = blockIdx.x; // (a persistent workgroup takes its frames from a.work instead, see below)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = NT / 64;
     constexpr int q = Q; // == a.q (the host picks the instantiation)
@@ -408,21 +409,14 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
     }
 
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
-    for (int i = tid; i < TC * QP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
-    if (tid == 0) flag[0] = 0;
     __syncthreads();
 
-    const float *Lch = a.Lch + (size_t)frame * N * (q - 1);
-    float *LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
+    const float *Lch = nullptr; // of the frame being decoded (set per frame below)
+    float *LLRo = nullptr;
     const bool active = lane < q - 1;          // lanes 0..q-2 <-> field elements 1..q-1
     const int sym = active ? lane + 1 : 0;     // lane q-1 carries element 0 (value 0, :250)
     constexpr int CPW = 96 * 64 / NT; // columns per wave whose channel vector stays in registers (N <= 96)
     float lch[CPW];
-#pragma unroll
-    for (int ci = 0; ci < CPW; ci++) {
-        const int col = min(wave + ci * nwaves, N - 1);
-        lch[ci] = active ? Lch[col * (q - 1) + lane] : 0.0f;
-    }
     // The graph does not change between iterations: for narrow codes (dv <= 2) each lane keeps, per column and edge, the
     // LDS offset of ITS entry of the check thread's max array, E[mul(sym, h)][thr], so an iteration starts with that one
     // read instead of three dependent table look-ups.  E[0][thr] (the reference's EMS_L_c2v[0]) is the same read in the
@@ -480,6 +474,33 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         }
     };
     int it = 0, ok = 0;
+    // Frames differ in their iteration counts by a factor of 20 (a frame leaves when its syndrome is zero), and one frame fills a
+    // CU: dispatched one workgroup per frame the CUs ended up 17 % apart (12.2 ms where the sum of the iterations says 10.1,
+    // tools/nb_fixed_cost.py).  PERSISTENT workgroups -- the grid fills the chip once -- take frame after frame from a counter, and
+    // load the graph tables and the GF table into LDS once instead of once per frame.
+    for (;;) {
+    if (a.work) {
+        if (tid == 0) flag[1] = atomicAdd(a.work, 1);
+        __syncthreads();
+        frame = __builtin_amdgcn_readfirstlane(flag[1]); // uniform: the frame's pointers then live in scalar registers
+    }
+    if (frame >= a.B) break;
+    Lch = a.Lch + (size_t)frame * N * (q - 1);
+    LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
+    {
+        int lo = lane; // opaque per frame: left alone the compiler keeps the six load offsets of a lane across the whole frame loop
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int ci = 0; ci < CPW; ci++) {
+            const int col = min(wave + ci * nwaves, N - 1);
+            lch[ci] = active ? Lch[col * (q - 1) + lo] : 0.0f;
+        }
+    }
+    for (int i = tid; i < TC * QP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    it = 0;
+    ok = 0;
 #ifdef NB_STAMP
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define NB_T(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[i] += tn - tprev; tprev = tn; }
@@ -621,6 +642,9 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
             for (int k = 1; k < q; k++) o[k - 1] = 0.0f;
         }
     }
+    if (!a.work) break;
+    __syncthreads(); // the max arrays, the symbols and flag[1] are reused by the next frame
+    } // next frame
 }
 
 // Demodulate, BPSK branch (LDPC_Decoder.cpp:139-157): one thread per (frame, symbol, element).
