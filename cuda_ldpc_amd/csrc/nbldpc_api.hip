@@ -344,7 +344,22 @@ extern "C" int nbldpc_tmm_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     const size_t lds = tmm_lds_bytes(c->N, c->M, c->q, c->dv, c->dc, layered != 0);
     TmmKernel k = tmm_kernel(c->q, layered != 0);
     CLDPC_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), NBLDPC_EHIP);
-    hipLaunchKernelGGL(k, dim3(B), dim3(kTmmThreads), lds, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    int occ = 0, dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k, kTmmThreads, lds) == hipSuccess && occ > 0 && B > ncu * occ &&
+        !getenv("NBLDPC_NO_PERSIST")) { // persistent workgroups and a frame counter, as in nbldpc_ems_decode_batch
+        void *work = nullptr;
+        CLDPC_HIP(hipMallocAsync(&work, sizeof(int), st), NBLDPC_ENOMEM);
+        CLDPC_HIP(hipMemsetAsync(work, 0, sizeof(int), st), NBLDPC_EHIP);
+        a.work = (int *)work;
+        hipLaunchKernelGGL(k, dim3(ncu * occ), dim3(kTmmThreads), lds, st, a);
+        const hipError_t le = hipGetLastError();
+        CLDPC_HIP(hipFreeAsync(work, st), NBLDPC_EHIP);
+        CLDPC_HIP(le, NBLDPC_EHIP);
+        return NBLDPC_OK;
+    }
+    hipLaunchKernelGGL(k, dim3(B), dim3(kTmmThreads), lds, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }

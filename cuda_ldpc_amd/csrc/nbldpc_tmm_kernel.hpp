@@ -47,6 +47,7 @@ struct TmmArgs {
     const int *row_order, *level_begin;       // layered: rows sorted by level [M], first row of each level [levels+1]
     const unsigned char *mul;                 // [q][q]
     int N, M, q, dv, dc, B, max_iter, levels;
+    int *work = nullptr; // != nullptr: persistent workgroups take frame after frame from this counter (zeroed by the host), see k_nb_ems
 };
 
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float nb_dpp_min(float v)
@@ -77,7 +78,7 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
 {
     constexpr int q = Q, NT = kTmmThreads, nwaves = NT / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int frame = blockIdx.x;
+    int frame = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, M = a.M, dv = a.dv, dc = a.dc, NE = N * dv, TC = M * dc;
@@ -107,17 +108,7 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
     if (LAYERED)
         for (int i = tid; i <= a.levels; i += NT) t_lvl[i] = (unsigned short)a.level_begin[i];
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
-    for (int i = tid; i < TC * q; i += NT) C2V[i] = 0.0f; // :395-404
-    if (tid == 0) flag[0] = 0;
     const bool act = lane < q;
-    // initial vectors (:363-393): max over L_ch, LLR[0] = max, LLR[k] = max - L_ch[k-1]
-    const float *Lch = a.Lch + (size_t)frame * N * (q - 1);
-    for (int col = wave; col < N; col += nwaves) {
-        const float lc = (lane < q - 1) ? Lch[col * (q - 1) + lane] : -__builtin_inff();
-        const float mx = nb_wave_max(lc);
-        const float lm = (lane >= 1 && act) ? Lch[col * (q - 1) + lane - 1] : 0.0f;
-        if (act) LLR[col * q + lane] = (lane == 0) ? mx : mx - lm;
-    }
     __syncthreads();
 
     auto uni = [&](const unsigned short *t, int i) -> int { return __builtin_amdgcn_readfirstlane((int)t[i]); }; // wave-uniform table entry
@@ -237,6 +228,27 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
     };
 
     int it = 0, ok = 0;
+    for (;;) { // frames of this workgroup: its own (one workgroup per frame) or, persistent, the next of the batch (see k_nb_ems)
+    if (a.work) {
+        if (tid == 0) flag[1] = atomicAdd(a.work, 1);
+        __syncthreads();
+        frame = __builtin_amdgcn_readfirstlane(flag[1]);
+    }
+    if (frame >= a.B) break;
+    for (int i = tid; i < TC * q; i += NT) C2V[i] = 0.0f; // :395-404
+    if (tid == 0) flag[0] = 0;
+    {   // initial vectors (:363-393): max over L_ch, LLR[0] = max, LLR[k] = max - L_ch[k-1]
+        const float *Lch = a.Lch + (size_t)frame * N * (q - 1);
+        for (int col = wave; col < N; col += nwaves) {
+            const float lc = (lane < q - 1) ? Lch[col * (q - 1) + lane] : -__builtin_inff();
+            const float mx = nb_wave_max(lc);
+            const float lm = (lane >= 1 && act) ? Lch[col * (q - 1) + lane - 1] : 0.0f;
+            if (act) LLR[col * q + lane] = (lane == 0) ? mx : mx - lm;
+        }
+    }
+    __syncthreads();
+    it = 0;
+    ok = 0;
     while (it < a.max_iter) {
         it++;
         // ---- variable nodes: (flooding) LLR += c2v in ascending d (:425-433); first-minimum decision (:434 / :602-605)
@@ -293,6 +305,9 @@ template <int Q, bool LAYERED> __global__ __launch_bounds__(kTmmThreads) void k_
             const int thr = i / q;
             a.c2v[(size_t)frame * TC * q + i] = (thr % dc < t_cn_w[thr / dc]) ? C2V[i] : 0.0f;
         }
+    if (!a.work) break;
+    __syncthreads(); // LLR, C2V, the symbols and flag[1] are reused by the next frame
+    } // next frame
 }
 
 } // namespace cldpc
