@@ -32,7 +32,7 @@ struct nbldpc_code {
     int levels = 0;
     bool tmm_ok = false;
     int zero_coeff = 0; // an edge with coefficient 0 exists (EMS only, see nbldpc_code_create)
-    int persist_grid = 0; // k_nb_ems: workgroups that fill the chip once (CUs x workgroups per CU)
+    int persist_grid = 0; // k_nb_ems / k_nb_ems_wide: workgroups that fill the chip once (CUs x workgroups per CU)
     bool hbm = false;   // decoded by k_nb_ems_hbm (state in a global-memory workspace): LDS too small or rows heavier than kNbMaxW
 };
 
@@ -253,7 +253,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         if (hbm) e = hipFuncSetAttribute((const void *)k_nb_ems_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256); // GF(256) table
         else e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        if (!r && !hbm && q <= 64) {
+        if (!r && !hbm) {
             int occ = 0, dev = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
@@ -305,7 +305,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         CLDPC_HIP(le, NBLDPC_EHIP);
         return NBLDPC_OK;
     }
-    if (c->q <= 64 && c->persist_grid > 0 && B > c->persist_grid && !getenv("NBLDPC_NO_PERSIST")) { // (env: experiments)
+    if (c->persist_grid > 0 && B > c->persist_grid && !getenv("NBLDPC_NO_PERSIST")) { // (env: experiments)
         // persistent workgroups and a frame counter (k_nb_ems): stream-ordered, so that calls on different streams do not share it
         void *work = nullptr;
         CLDPC_HIP(hipMallocAsync(&work, sizeof(int), st), NBLDPC_ENOMEM);

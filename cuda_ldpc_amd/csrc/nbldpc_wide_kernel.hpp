@@ -24,7 +24,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems_wide(NbA
     static_assert(Q % 64 == 0 && NT % Q == 0, "a vector is a whole number of waves, the workgroup a whole number of vectors");
     constexpr int GW = Q / 64, NG = NT / Q, QP = Q + 1, q = Q;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int frame = blockIdx.x;
+    int frame = blockIdx.x; // (a persistent workgroup takes its frames from a.work instead, see k_nb_ems)
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = tid / Q, el = tid - grp * Q, wv = el >> 6; // wave of this thread inside its group
     const int N = a.N, M = a.M, dv = a.dv, dc = a.dc;
@@ -47,16 +47,27 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems_wide(NbA
         t_cn_src[i] = (unsigned short)a.cn_src[i]; t_cn_gf[i] = (unsigned short)a.cn_gf[i]; t_cn_vn[i] = (unsigned short)a.cn_vn[i];
     }
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
-    for (int i = tid; i < TC * QP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
-    if (tid == 0) flag[0] = 0;
     __syncthreads();
-
-    const float *Lch = a.Lch + (size_t)frame * N * (q - 1);
-    float *LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
+    const float *Lch = nullptr; // of the frame being decoded
+    float *LLRo = nullptr;
     const bool active = el < q - 1;
     const int sym = active ? el + 1 : 0;
     const int rounds_a = (N + NG - 1) / NG, rounds_b = (NE + NG - 1) / NG;
     int it = 0, ok = 0;
+    for (;;) { // frames of this workgroup: its own, or (persistent) the next of the batch, see k_nb_ems
+    if (a.work) {
+        if (tid == 0) flag[1] = atomicAdd(a.work, 1);
+        __syncthreads();
+        frame = __builtin_amdgcn_readfirstlane(flag[1]);
+    }
+    if (frame >= a.B) break;
+    Lch = a.Lch + (size_t)frame * N * (q - 1);
+    LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
+    for (int i = tid; i < TC * QP; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    it = 0;
+    ok = 0;
     while (it < a.max_iter) {
         it++;
         // ---- A: variable nodes (:202-251), one per group and round ---------------------------------------------------
@@ -174,6 +185,9 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems_wide(NbA
             for (int k = 1; k < q; k++) o[k - 1] = 0.0f;
         }
     }
+    if (!a.work) break;
+    __syncthreads(); // the max arrays, the symbols and flag[1] are reused by the next frame
+    } // next frame
 }
 
 } // namespace cldpc
