@@ -296,9 +296,11 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         const size_t cap = std::max<size_t>(1, ((size_t)2 << 30) / (slot * sizeof(float)));
         const int slots = (int)std::min<size_t>({(size_t)B, (size_t)1024, cap});
         void *ws = nullptr;
-        CLDPC_HIP(hipMallocAsync(&ws, (size_t)slots * slot * sizeof(float), st), NBLDPC_ENOMEM);
+        CLDPC_HIP(hipMallocAsync(&ws, (size_t)slots * slot * sizeof(float) + 64, st), NBLDPC_ENOMEM);
         a.ws = (float *)ws;
         a.ws_stride = slot;
+        a.work = (int *)((char *)ws + (size_t)slots * slot * sizeof(float)); // frame counter behind the slots
+        CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
         hipLaunchKernelGGL(k_nb_ems_hbm, dim3(slots), dim3(kNbHbmThreads), (size_t)c->q * c->q, st, a);
         const hipError_t le = hipGetLastError();
         CLDPC_HIP(hipFreeAsync(ws, st), NBLDPC_EHIP);

@@ -89,7 +89,14 @@ __global__ __launch_bounds__(kNbHbmThreads) void k_nb_ems_hbm(NbArgs a)
     int *outs = reinterpret_cast<int *>(LLRw + (size_t)N * (q - 1)); // [N]
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
 
-    for (int frame = blockIdx.x; frame < a.B; frame += gridDim.x) {
+    __shared__ int next_frame;
+    for (int frame = blockIdx.x;; frame += gridDim.x) { // a.work: frames from a counter (they differ 20x in iterations), else strided
+        if (a.work) {
+            if (tid == 0) next_frame = atomicAdd(a.work, 1);
+            __syncthreads();
+            frame = __builtin_amdgcn_readfirstlane(next_frame);
+        }
+        if (frame >= a.B) break;
         const float *Lch = a.Lch + (size_t)frame * N * (q - 1);
         float *LLRo = a.LLR ? a.LLR + (size_t)frame * N * (q - 1) : nullptr;
         for (int i = tid; i < TC * q; i += NT) E[i] = 0.0f; // L_c2v = 0 (:185-193): (0 - 0) / 1.2 == +0
