@@ -82,6 +82,7 @@ struct QcArgs {
     // the reference rule (LDPC_Decoder.cu:134-153) with Num_Frames_OneTime = 1 -- its outputs are those of that
     // iteration, and the workgroup leaves when all of its frames have stopped
     int per_frame;
+    int *work = nullptr;        // k_qc2p: one frame-pair counter per XCD (8 ints, zeroed by the host)
     int *iters;                 // [F] iterations executed per frame (per_frame only)
 #ifdef QC_STAMPS
     unsigned long long *stamps; // tools/qc_phase_probe.hip only: [nWG][QC_STAMPS] s_memtime stamps of wave 0
@@ -512,267 +513,16 @@ template <int OFF> __device__ __forceinline__ void lds_st2_imm(int base, v2f32 v
 //     lanes 32-63 those of frame 1, every lane merges one frame, two more swaps hand both results to all lanes -- 5 swaps
 //     and one merge per lane instead of 6 swaps + 6 copies and two merges;
 //   * magnitudes merge as unsigned integers (same order as non-negative floats, +inf included; no canonicalising v_max).
-template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc2(QcArgs a)
-{
-    constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, GJ = GM::GJ, ZB = GM::ZB, WCH = GM::WCH;
-    constexpr int RPT = GM::RPT, CPT = GM::CPT, NCG = GM::NCG, MSG = GM::MSG;
-    static_assert(NF == 2, "the half-row kernel carries a frame pair per lane");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
-    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (wg >= a.nWG) return;
-
-    const int F = a.F;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, h = lane >> 5;
-    const int jq = wave / ZB, t = (wave - jq * ZB) * 32 + (lane & 31);
-    const int cg = jq * 2 + h;  // column group of this half-wave
-    const int f0 = wg * NF;
-    int *lds_flag = reinterpret_cast<int *>(lds + GM::flag_byte);
-
-    // row j = jq + rr*GJ, this thread's edges pp = h*WCH + i
-    const int rbase = ((jq * WC + h * WCH) * Z + t) * MSG;   // + (rr*GJ*WC + i)*Z*MSG
-    const int sbase = (GM::Sslot + cg * Z + t) * MSG;        // + cc*NCG*Z*MSG
-    int saddr[RPT][WCH]; // byte addresses of the S values of this thread's edges
-    v2f32 Rr[RPT][WCH];  // this thread's previous outputs R_p (Memory_RQ = 0 at the start, LDPC_Decoder.cu:82)
-    int e0v[RPT], wrv[RPT];
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-        e0v[rr] = a.rowptr[jq + rr * GJ];
-        wrv[rr] = a.rowptr[jq + rr * GJ + 1] - e0v[rr];
-    }
-    int wcv[CPT];
-#pragma unroll
-    for (int cc = 0; cc < CPT; cc++) wcv[cc] = a.wv[cg + cc * NCG];
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-        QcCnEdge ed[WCH];
-#pragma unroll
-        for (int i = 0; i < WCH; i++) ed[i] = a.cn_edges[e0v[rr] + min(h * WCH + i, wrv[rr] - 1)];
-#pragma unroll
-        for (int i = 0; i < WCH; i++) {
-            int c = t + ed[i].shift;
-            c = (c >= Z) ? c - Z : c;
-            const int slot = (h * WCH + i < wrv[rr]) ? GM::Sslot + ed[i].col * Z + c : GM::inf_slot;
-            saddr[rr][i] = slot * MSG;
-            Rr[rr][i] = v2f32{0.0f, 0.0f};
-            lds_st2(rbase + (rr * GJ * WC + i) * Z * MSG, Rr[rr][i]);
-        }
-    }
-    v2f32 yreg[CPT];
-    int raddr[CPT][WV];
-#pragma unroll
-    for (int cc = 0; cc < CPT; cc++) {
-        const int l = cg + cc * NCG;
-        QcVnEdge ed[WV];
-#pragma unroll
-        for (int k = 0; k < WV; k++) ed[k] = a.vn_edges[l * WV + min(k, wcv[cc] - 1)];
-        yreg[cc] = a.y_raw ? *reinterpret_cast<const v2f32 *>(a.y_raw + (size_t)(l * Z + t) * F + f0)
-                           : *reinterpret_cast<const v2f32 *>(a.y + ((size_t)wg * (L * Z) + l * Z + t) * NF);
-#pragma unroll
-        for (int k = 0; k < WV; k++) {
-            int r = t - ed[k].shift;
-            r = (r < 0) ? r + Z : r;
-            raddr[cc][k] = ((k < wcv[cc]) ? ed[k].e * Z + r : GM::zero_slot) * MSG;
-        }
-    }
-    if (tid < NF) {
-        reinterpret_cast<float *>(lds)[GM::zero_slot * NF + tid] = 0.0f;
-        reinterpret_cast<float *>(lds)[GM::inf_slot * NF + tid] = __builtin_inff();
-        lds_flag[tid] = 0;
-        lds_flag[NF + tid] = 0;
-    }
-    unsigned long long hist = 0;
-    unsigned done = 0; // per-frame exit, see k_qc
-    constexpr unsigned ALL = (1u << NF) - 1u;
-#ifdef QC_STAMPS
-    int nst = 0;
-    auto stamp = [&](unsigned long long v) { if (tid == 0 && nst < QC_STAMPS) a.stamps[(size_t)wg * QC_STAMPS + nst++] = v; };
-    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    stamp(((unsigned long long)xcc << 32) | hwid);
-    stamp(__builtin_amdgcn_s_memtime());
-    if (a.stagger && ((hwid >> 16) & 1))
-        for (int i = 0; i < a.stagger; i += 64 * 16) __builtin_amdgcn_s_sleep(16);
-#endif
-    __syncthreads();
-#ifdef QC_STAMPS
-    stamp(__builtin_amdgcn_s_memtime());
-#endif
-
-    // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.  0 + R_0 is a real addition:
-    // R_0 may be -0.0f (magnitude 0, sign -1) and (+0) + (-0) = +0 is what the reference computes.
-    auto vn_phase = [&](bool (&bad)[NF]) {
-        constexpr int CB = (CPT * WV <= 12) ? CPT : 1; // columns with reads in flight together
-        static_for<CPT / CB>([&](auto C0) {
-            constexpr int c0 = decltype(C0)::value * CB;
-            v2f32 R[CB][WV];
-#pragma unroll
-            for (int ci = 0; ci < CB; ci++)
-#pragma unroll
-                for (int k = 0; k < WV; k++) R[ci][k] = lds_ld2(raddr[c0 + ci][k]);
-            static_for<CB>([&](auto CI) {
-                constexpr int ci = decltype(CI)::value, cc = c0 + ci;
-                v2f32 S = v2f32{0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < WV; k++) S = S + R[ci][k];
-                S = S + yreg[cc];
-                lds_st2_imm<cc * NCG * Z * MSG>(sbase, S);
-                if (HIST) {
-                    const bool in_len = ((cg + cc * NCG) * Z + t) < a.length;
-                    bad[0] = bad[0] || (in_len && S.x < 0);
-                    bad[1] = bad[1] || (in_len && S.y < 0);
-                }
-            });
-            if (CB < CPT) __builtin_amdgcn_sched_barrier(0);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the stores above are invisible to the compiler's counters
-    };
-    auto flags_publish = [&](const bool (&bad)[NF], int it) { // two sets of flag words by iteration parity, see k_qc
-#pragma unroll
-        for (int v = 0; v < NF; v++)
-            if (bad[v]) lds_flag[(it & 1) * NF + v] = 1;
-    };
-    auto flags_collect = [&](int it) -> int {
-        int flag = 0;
-        if (tid < NF) {
-            flag = lds_flag[(it & 1) * NF + tid] ? 0 : 1;
-            lds_flag[((it + 1) & 1) * NF + tid] = 0;
-            if (flag && it <= 64) hist |= (1ull << (it - 1));
-        }
-        return flag;
-    };
-    auto emit = [&](unsigned mask, bool (&bad)[NF]) {
-        unsigned *obits = a.bits; // opaque copies, see k_qc
-        float *oapp = a.app;
-        asm volatile("" : "+s"(obits), "+s"(oapp));
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int n = (cg + cc * NCG) * Z + t;
-            float S[NF];
-            lds_ld<NF>(S, lds, sbase + cc * NCG * Z * MSG);
-#pragma unroll
-            for (int v = 0; v < NF; v++) {
-                if (HIST && !((mask >> v) & 1u)) continue; // workgroup-uniform
-                const bool neg = S[v] < 0;
-                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
-                const unsigned long long m = __ballot(neg); // one 32-bit word per half-wave, see k_qc
-                if ((tid & 31) == 0 && f0 + v < F) obits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
-                if (oapp && f0 + v < F) oapp[(size_t)n * F + f0 + v] = S[v];
-            }
-        }
-    };
-    auto retire = [&](int it) -> bool { // per-frame exit, see k_qc
-        unsigned newly = 0;
-#pragma unroll
-        for (int v = 0; v < NF; v++)
-            if (!lds_flag[(it & 1) * NF + v]) newly |= 1u << v;
-        newly &= ~done;
-        if (newly) {
-            bool unused[NF];
-            emit(newly, unused);
-            if (tid < NF && ((newly >> tid) & 1u) && f0 + tid < F) a.iters[f0 + tid] = it;
-            done |= newly;
-        }
-        return done == ALL;
-    };
-
-    for (int it = 1; it < a.max_iter; it++) {
-        bool bad[NF];
-#pragma unroll
-        for (int v = 0; v < NF; v++) bad[v] = false;
-        __builtin_amdgcn_s_setprio(QC_PRIO_VN);
-        vn_phase(bad);
-        if (HIST) flags_publish(bad, it);
-        __syncthreads();
-        __builtin_amdgcn_s_setprio(QC_PRIO_CN);
-#ifdef QC_STAMPS
-        stamp(__builtin_amdgcn_s_memtime());
-#endif
-        if (HIST) {
-            (void)flags_collect(it);
-            if (a.per_frame && retire(it)) break;
-        }
-
-        // CN phase (LDPC_Decoder.cu:279-314)
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) {
-            CnAcc acc[NF];
-            {   // in two batches: every load in flight holds a register pair, and 6 waves per SIMD leave 80 registers per lane
-                constexpr int CHK = (WCH > 6) ? (WCH + 1) / 2 : WCH;
-#pragma unroll
-                for (int c0 = 0; c0 < WCH; c0 += CHK) {
-                    v2f32 Sv[CHK];
-#pragma unroll
-                    for (int i = 0; i < CHK && c0 + i < WCH; i++) Sv[i] = lds_ld2(saddr[rr][c0 + i]);
-#pragma unroll
-                    for (int i = 0; i < CHK && c0 + i < WCH; i++) Rr[rr][c0 + i] = Sv[i] - Rr[rr][c0 + i]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
-                    if (c0 + CHK < WCH) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#if QC_ACC_RUNNING
-#pragma unroll
-            for (int v = 0; v < NF; v++) acc[v].init();
-#pragma unroll
-            for (int i = 0; i < WCH; i++) {
-                acc[0].add(Rr[rr][i].x);
-                acc[1].add(Rr[rr][i].y);
-            }
-#else
-            cn_two_smallest<WCH, 2>(reinterpret_cast<const float *>(&Rr[rr][0]), acc[0].m1, acc[0].m2, acc[0].sgn);
-            cn_two_smallest<WCH, 2>(reinterpret_cast<const float *>(&Rr[rr][0]) + 1, acc[1].m1, acc[1].m2, acc[1].sgn);
-#endif
-            // merge the two halves of the row: the two smallest of {m1,m2} U {m1',m2'}, XOR of the signs
-            uint32_t a1 = f2u(acc[0].m1), b1 = f2u(acc[1].m1), a2 = f2u(acc[0].m2), b2 = f2u(acc[1].m2), as = acc[0].sgn, bs = acc[1].sgn;
-            swap32(a1, b1); // lanes 0-31: (own, other half's) value of frame 0; lanes 32-63: (other half's, own) value of frame 1
-            swap32(a2, b2);
-            swap32(as, bs);
-            const uint32_t m1 = min(a1, b1);
-            uint32_t m2u = min(min(max(a1, b1), a2), b2);
-            uint32_t keyu = (m1 ^ m2u) ^ ((as ^ bs) & 0x80000000u);
-            uint32_t m2v = m2u, keyv = keyu;
-            swap32(m2u, m2v);   // m2u: frame 0 (computed by lanes 0-31), m2v: frame 1, in every lane
-            swap32(keyu, keyv);
-            const float m2f[NF] = {u2f(m2u), u2f(m2v)};
-            const uint32_t key[NF] = {keyu, keyv};
-            __builtin_amdgcn_s_setprio(QC_PRIO_WR);
-            static_for<RPT * WCH>([&](auto I) {
-                constexpr int r_ = decltype(I)::value / WCH, i = decltype(I)::value % WCH;
-                if (r_ != rr) return;
-                v2f32 Rn;
-                Rn.x = cn_out(Rr[rr][i].x, m2f[0], key[0]);
-                Rn.y = cn_out(Rr[rr][i].y, m2f[1], key[1]);
-                Rr[rr][i] = Rn;
-                lds_st2_imm<(r_ * GJ * WC + i) * Z * MSG>(rbase, Rn);
-            });
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-#ifdef QC_STAMPS
-        stamp(__builtin_amdgcn_s_memtime());
-#endif
-    }
-
-    int flag = 0;
-    if (!(HIST && done == ALL)) { // final iteration: VN only, then outputs
-        bool bad[NF];
-#pragma unroll
-        for (int v = 0; v < NF; v++) bad[v] = false;
-        vn_phase(bad);
-        emit(~done, bad);
-        flags_publish(bad, a.max_iter);
-        __syncthreads();
-        flag = flags_collect(a.max_iter);
-    }
-#ifdef QC_STAMPS
-    stamp(__builtin_amdgcn_s_memtime());
-#endif
-    if (tid < NF && f0 + tid < F) {
-        const bool stopped = HIST && ((done >> tid) & 1u);
-        a.D[(size_t)L * Z * F + f0 + tid] = stopped ? 1 : flag;
-        if (HIST && a.hist) a.hist[f0 + tid] = hist;
-        if (HIST && a.per_frame && !stopped) a.iters[f0 + tid] = a.max_iter;
-    }
-}
+#define QC2_NAME k_qc2
+#define QC2_PERSIST 0
+#include "bldpc_qc2_body.inc"
+#undef QC2_NAME
+#undef QC2_PERSIST
+#define QC2_NAME k_qc2p
+#define QC2_PERSIST 1
+#include "bldpc_qc2_body.inc"
+#undef QC2_NAME
+#undef QC2_PERSIST
 
 // Regroup the reference's frame-fastest Channel_Out [N][F] into per-workgroup slabs [F/NF][N][NF] so that the
 // decode kernel's loads are contiguous along the circulant dimension (the reference layout would cost every
@@ -1047,7 +797,8 @@ __global__ __launch_bounds__(256) void k_iters_max(const int *iters, int F, int 
 
 // ---------------------------------------------------------------------------------------------
 using QcKernel = void (*)(QcArgs);
-struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; int U, CPT, regstate; };
+struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; int U, CPT, regstate; QcKernel fn_pf = nullptr; };
+// fn_pf: persistent kernel for the per-frame exit (k_qc2p), or null
 // tag "compressed" (U != 0): J = L = 0 (any), WC = row slots, lds_bytes computed per code; tag "regstate": L = 0 (any)
 
 // Ahead-of-time variants: one per block-matrix geometry of the reference's matrix set whose message
@@ -1071,7 +822,7 @@ inline const QcVariant *qc_variants(int *count)
 #define X2(NF, J, L, Z, WC, WV, GJ, MINW)                                                                 \
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::TPB,                            \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, false>, \
-     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow", 0, 0, 0},
+     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow", 0, 0, 0, k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>},
 #define XC(Z, U, G, CPT, WCS)                                                                              \
     {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
      k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0},
@@ -1138,6 +889,7 @@ struct QcPlan {
     int WVS = 0, lds_bytes = 0, lc = 0;
     char name[96] = "qc_lds(unavailable)";
     mutable int ran_to_max = 0; // BATCH_GLOBAL: the previous batch did not stop before max_iter (a performance hint, never a result)
+    int persist_grid = 0; // k_qc2p: workgroups that fill the chip once (a multiple of 8)
     mutable bool y_in_place = false; // this decode call hands the kernels the caller's [N][F] array itself (qc_decode)
     // bldpc_decode_statistic: per-frame error counts wanted from the pass that unpacks the hard bits (single-launch modes only)
     mutable int *stat_errs = nullptr;
@@ -1356,6 +1108,14 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     CLDPC_HIP(hipMemcpy(q->d_wv, wvb.data(), wvb.size(), hipMemcpyHostToDevice), BLDPC_EHIP);
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, generic ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, generic ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
+    if (v.fn_pf) {
+        CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_pf, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
+        int occ = 0, dev = 0, ncu = 0;
+        CLDPC_HIP(hipGetDevice(&dev), BLDPC_EHIP);
+        CLDPC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev), BLDPC_EHIP);
+        CLDPC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)v.fn_pf, v.threads, (size_t)v.lds_bytes + 16), BLDPC_EHIP);
+        q->persist_grid = std::max(8, ncu * std::max(1, occ) / 8 * 8);
+    }
     q->frames_per_wg = v.NF;
     snprintf(q->name, sizeof(q->name), "qc_lds_%s<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.tag, v.NF, J, L, v.Z, v.WC, generic ? Wv : v.WV,
              v.G, v.MINW, v.threads, q->lds_bytes);
@@ -1384,7 +1144,7 @@ inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStre
 // y here is the regrouped buffer produced by qc_regroup.
 inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
                      unsigned long long *hist, unsigned *bits, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                     int *iters = nullptr, bool expand = true)
+                     int *iters = nullptr, bool expand = true, int *work = nullptr)
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
@@ -1399,9 +1159,17 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 #ifdef QC_STAMPS
     a.stamps = g_qc_stamps; a.stagger = g_qc_stagger;
 #endif
-    const unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
+    unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
+    QcKernel fn = hist ? v.fn_hist : v.fn;
+    if (a.per_frame && v.fn_pf && work && q->persist_grid > 0 && grid > (unsigned)q->persist_grid && !getenv("BLDPC_NO_PERSIST")) {
+        // per-frame exit on the half-row kernel: persistent workgroups, one frame-pair counter per XCD (k_qc2p)
+        CLDPC_HIP(hipMemsetAsync(work, 0, 8 * sizeof(int), st), BLDPC_EHIP);
+        a.work = work;
+        fn = v.fn_pf;
+        grid = (unsigned)q->persist_grid;
+    }
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(hist ? v.fn_hist : v.fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(v.threads), q->lds_bytes, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     const int NW = q->L * q->Z / 32;
     if (expand) {
@@ -1437,7 +1205,7 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     }
     if (exit_mode == BLDPC_EXIT_PER_FRAME) { // every workgroup leaves when its own frames have stopped; nothing to wait for
         *itera = max_iter;
-        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters);
+        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters, true, (int *)and_ws);
     }
     // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are flagged.  No
     // workgroup can know that iteration while it runs, so it is found first and the batch then decoded with exactly that
