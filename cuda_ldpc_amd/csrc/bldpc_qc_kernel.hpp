@@ -154,311 +154,16 @@ template <int... Is, typename Fn> __device__ __forceinline__ void static_for_imp
 }
 template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB, GM::MINW) void k_qc(QcArgs a)
-{
-    constexpr int NF = GM::NF, L = GM::L, Z = GM::Z, WC = GM::WC, WV = GM::WV, G = GM::G;
-    constexpr int RPT = GM::RPT, CPT = GM::CPT, MSG = GM::MSG;
-    constexpr bool USE_PRIO = GM::lds_bytes * 2 <= 160 * 1024; // stage priorities matter between the workgroups that share a CU (see k_qc2)
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    // XCD-aware workgroup id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
-    // contiguous range of frames so the 4-byte-per-frame rows of y are fetched into one L2 only.
-    const int chunk = (a.nWG + 7) >> 3;
-    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (wg >= a.nWG) return;
-
-    const int F = a.F;
-    const int tid = threadIdx.x;
-    const int g = tid / Z, t = tid - g * Z;
-    const int f0 = wg * NF; // first frame of this workgroup
-    int *lds_flag = reinterpret_cast<int *>(lds + GM::flag_byte); // [NF]
-
-    // ---- prologue: rotated slot indices, channel values, zeroed R ----------------------------
-    // row j = g + rr*G, block pp:   R slot  (j*WC + pp)*Z + t               (aligned)
-    //                               S slot  Sslot + col*Z + (t+s) mod Z     (rotated)
-    const int rbase = (g * WC * Z + t) * MSG;          // + (rr*G*WC + pp)*Z*MSG as immediate offsets
-    const int sbase = (GM::Sslot + g * Z + t) * MSG;   // + cc*G*Z*MSG
-    unsigned saddr[RPT][(WC + 1) / 2];                 // S slots of the row's neighbours, packed 2 x 16 bit
-    constexpr bool UNPACKED = RPT * WC <= 16;          // few enough to keep as byte addresses (saves 2 VALU per edge and iteration)
-    int saddr_u[UNPACKED ? RPT : 1][UNPACKED ? WC : 1];
-    float Rr[RPT][WC][NF];                             // this thread's previous outputs R_p: it wrote them, it keeps them (see k_qc2)
-    // All table gathers are issued unconditionally (index clamped into the row / column) and only then
-    // consumed: predicated loads would be waited for one by one, ~0.4 us each under load.
-    int e0v[RPT], wrv[RPT];
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-        e0v[rr] = a.rowptr[g + rr * G];
-        wrv[rr] = a.rowptr[g + rr * G + 1] - e0v[rr];
-    }
-    int wcv[CPT];
-#pragma unroll
-    for (int cc = 0; cc < CPT; cc++) wcv[cc] = a.wv[g + cc * G];
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-        QcCnEdge ed[WC];
-#pragma unroll
-        for (int pp = 0; pp < WC; pp++) ed[pp] = a.cn_edges[e0v[rr] + min(pp, wrv[rr] - 1)];
-#pragma unroll
-        for (int pp = 0; pp < WC; pp++) {
-            int c = t + ed[pp].shift;
-            c = (c >= Z) ? c - Z : c;
-            const int slot = (pp < wrv[rr]) ? GM::Sslot + ed[pp].col * Z + c : GM::inf_slot;
-            if (pp & 1) saddr[rr][pp / 2] |= (unsigned)slot << 16;
-            else saddr[rr][pp / 2] = (unsigned)slot;
-            if (UNPACKED) saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0] = slot * MSG;
-            const float zero[NF] = {};
-            lds_st<NF>(lds, rbase + (rr * G * WC + pp) * Z * MSG, zero); // Memory_RQ = 0 (LDPC_Decoder.cu:82)
-#pragma unroll
-            for (int v = 0; v < NF; v++) Rr[rr][pp][v] = 0.0f;
-        }
-    }
-    float yreg[CPT][NF];
-    int raddr[CPT][WV]; // byte addresses of the R messages of each variable's edges
-#pragma unroll
-    for (int cc = 0; cc < CPT; cc++) {
-        const int l = g + cc * G;
-        QcVnEdge ed[WV];
-#pragma unroll
-        for (int k = 0; k < WV; k++) ed[k] = a.vn_edges[l * WV + min(k, wcv[cc] - 1)];
-        {   // one coalesced NF*4-byte load per lane (frames >= F were zero-filled by k_regroup_y)
-            // frames >= F were zero-filled by k_regroup_y; the in-place form is only used when every workgroup has NF frames
-            typename Msg<NF>::T yv = (NF == 2 && a.y_raw)
-                                         ? *reinterpret_cast<const typename Msg<NF>::T *>(a.y_raw + (size_t)(l * Z + t) * F + f0)
-                                         : *reinterpret_cast<const typename Msg<NF>::T *>(a.y + ((size_t)wg * (L * Z) + l * Z + t) * NF);
-            __builtin_memcpy(yreg[cc], &yv, sizeof(yv));
-        }
-#pragma unroll
-        for (int k = 0; k < WV; k++) {
-            int r = t - ed[k].shift;
-            r = (r < 0) ? r + Z : r;
-            raddr[cc][k] = ((k < wcv[cc]) ? ed[k].e * Z + r : GM::zero_slot) * MSG;
-        }
-    }
-    if (tid < NF) {
-        reinterpret_cast<float *>(lds)[GM::zero_slot * NF + tid] = 0.0f;
-        reinterpret_cast<float *>(lds)[GM::inf_slot * NF + tid] = __builtin_inff();
-        lds_flag[tid] = 0;
-        lds_flag[NF + tid] = 0;
-    }
-    unsigned long long hist = 0; // used by threads tid < NF
-    unsigned done = 0;           // per-frame exit: frames of this workgroup that have stopped (workgroup-uniform)
-    constexpr unsigned ALL = (1u << NF) - 1u;
-#ifdef QC_STAMPS
-    int nst = 0;
-    auto stamp = [&](unsigned long long v) { if (tid == 0 && nst < QC_STAMPS) a.stamps[(size_t)wg * QC_STAMPS + nst++] = v; };
-    stamp(((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4));
-    stamp(__builtin_amdgcn_s_memtime());
-#endif
-    __syncthreads();
-#ifdef QC_STAMPS
-    stamp(__builtin_amdgcn_s_memtime());
-#endif
-
-    // VN phase (LDPC_Decoder.cu:188-210): S = ((0+R_0)+...+R_{w-1})+y, published aligned.
-    auto vn_phase = [&](bool (&bad)[NF]) {
-        constexpr int CB = (CPT * WV * NF <= 24) ? CPT : ((CPT % 3 == 0) ? 3 : ((CPT % 2 == 0) ? 2 : 1)); // columns with reads in flight together
-        static_for<CPT / CB>([&](auto C0) {
-            constexpr int c0 = decltype(C0)::value * CB;
-            float R[CB][WV][NF];
-#pragma unroll
-            for (int ci = 0; ci < CB; ci++)
-#pragma unroll
-                for (int k = 0; k < WV; k++) lds_ld<NF>(R[ci][k], lds, raddr[c0 + ci][k]);
-            static_for<CB>([&](auto CI) {
-                constexpr int ci = decltype(CI)::value, cc = c0 + ci;
-                float S[NF];
-#pragma unroll
-                for (int v = 0; v < NF; v++) S[v] = 0.0f;
-#pragma unroll
-                for (int k = 0; k < WV; k++) {
-#pragma unroll
-                    for (int v = 0; v < NF; v++) S[v] += R[ci][k][v];
-                }
-#pragma unroll
-                for (int v = 0; v < NF; v++) S[v] += yreg[cc][v];
-                lds_st_imm<NF, cc * G * Z * MSG>(sbase, S);
-                if (HIST) {
-                    const bool in_len = ((g + cc * G) * Z + t) < a.length;
-#pragma unroll
-                    for (int v = 0; v < NF; v++) bad[v] = bad[v] || (in_len && S[v] < 0);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the stores above are invisible to the compiler's counters
-    };
-
-    // per-iteration flag bookkeeping (LDPC_Decoder.cu:137-147).  Two sets of flag words, used by odd and even
-    // iterations in turn: the set read after this iteration's barrier is not written again before the next one, so
-    // every thread may read it (per-frame exit) while threads tid < NF clear the other set for the next iteration.
-    auto flags_publish = [&](const bool (&bad)[NF], int it) {
-#pragma unroll
-        for (int v = 0; v < NF; v++)
-            if (bad[v]) lds_flag[(it & 1) * NF + v] = 1; // same value from every writer
-    };
-    auto flags_collect = [&](int it) -> int {
-        int flag = 0;
-        if (tid < NF) {
-            flag = lds_flag[(it & 1) * NF + tid] ? 0 : 1;
-            lds_flag[((it + 1) & 1) * NF + tid] = 0;
-            if (flag && it <= 64) hist |= (1ull << (it - 1));
-        }
-        return flag;
-    };
-    // hard bits (and a-posteriori values) of the frames in `mask`, from the S values this thread has just published
-    auto emit = [&](unsigned mask, bool (&bad)[NF]) {
-        // opaque copies: keeps the output addresses from being computed ahead of the iteration loop and held (or spilled) through it
-        unsigned *obits = a.bits;
-        float *oapp = a.app;
-        asm volatile("" : "+s"(obits), "+s"(oapp));
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int n = (g + cc * G) * Z + t;
-            float S[NF];
-            lds_ld<NF>(S, lds, sbase + cc * G * Z * MSG); // own value, just written
-#pragma unroll
-            for (int v = 0; v < NF; v++) {
-                if (HIST && !((mask >> v) & 1u)) continue; // workgroup-uniform
-                const bool neg = S[v] < 0;
-                if (!HIST) bad[v] = bad[v] || (n < a.length && neg);
-                // hard bits leave packed, one 32-bit word per half-wave: Z % 32 == 0 keeps the 32 lanes of a
-                // half-wave inside one thread group, i.e. on 32 consecutive variables n .. n+31, n % 32 == 0.
-                const unsigned long long m = __ballot(neg);
-                if ((tid & 31) == 0 && f0 + v < F) obits[(size_t)(f0 + v) * GM::NW + (n >> 5)] = (unsigned)(m >> (tid & 32));
-                if (oapp && f0 + v < F) oapp[(size_t)n * F + f0 + v] = S[v];
-            }
-        }
-    };
-    // per-frame exit: frames whose flag has just come up leave with this iteration's outputs
-    auto retire = [&](int it) -> bool {
-        unsigned newly = 0;
-#pragma unroll
-        for (int v = 0; v < NF; v++)
-            if (!lds_flag[(it & 1) * NF + v]) newly |= 1u << v;
-        newly &= ~done;
-        if (newly) {
-            bool unused[NF];
-            emit(newly, unused);
-            if (tid < NF && ((newly >> tid) & 1u) && f0 + tid < F) a.iters[f0 + tid] = it;
-            done |= newly;
-        }
-        return done == ALL;
-    };
-
-    // ---- iterations 1 .. max_iter-1: VN, CN --------------------------------------------------
-    // One check row with exactly W edges (W <= WC; W < WC only where the row weight is wave-uniform, i.e. Z is whole waves:
-    // J32_L64_Z64 has rows of 5, 6 and 7 edges).  Rows lighter than W read the +inf slot in their padding positions.
-    auto s_load = [&](float (&d)[NF], int rr, int pp) {
-        if (UNPACKED) lds_ld<NF>(d, lds, saddr_u[UNPACKED ? rr : 0][UNPACKED ? pp : 0]);
-        else lds_ld<NF>(d, lds, (int)((pp & 1) ? (saddr[rr][pp / 2] >> 16) : (saddr[rr][pp / 2] & 0xffffu)) * MSG);
-    };
-    // All of a thread's check rows with W slots each (W <= WC; W < WC only where the rows, hence their weights, are wave-uniform,
-    // i.e. Z is whole waves: J32_L64_Z64 has rows of 5, 6 and 7 edges, paired by weight on the host).  The S values of every row
-    // are requested before the first row's arithmetic: with one workgroup per CU nobody else fills a load's latency.  Slots beyond
-    // a row's own weight read the +inf slot.
-    auto cn_rows = [&](auto WW) {
-        constexpr int W = decltype(WW)::value;
-        float Sv[RPT][W][NF];
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-            for (int pp = 0; pp < W; pp++) s_load(Sv[rr][pp], rr, pp);
-        static_for<RPT>([&](auto RR) {
-            constexpr int rr = decltype(RR)::value;
-#pragma unroll
-            for (int pp = 0; pp < W; pp++)
-#pragma unroll
-                for (int v = 0; v < NF; v++) Rr[rr][pp][v] = Sv[rr][pp][v] - Rr[rr][pp][v]; // Q = S - R  (LDPC_Decoder.cu:206-209), in place of R_p
-            float m2[NF];
-            uint32_t key[NF];
-#pragma unroll
-            for (int v = 0; v < NF; v++) {
-                CnAcc acc;
-                cn_two_smallest<W, NF>(&Rr[rr][0][v], acc.m1, acc.m2, acc.sgn);
-                m2[v] = acc.m2;
-                key[v] = acc.key();
-            }
-            if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_WR);
-            static_for<W>([&](auto PP) {
-                constexpr int pp = decltype(PP)::value;
-#pragma unroll
-                for (int v = 0; v < NF; v++) Rr[rr][pp][v] = cn_out(Rr[rr][pp][v], m2[v], key[v]);
-                lds_st_imm<NF, (rr * G * WC + pp) * Z * MSG>(rbase, Rr[rr][pp]);
-            });
-            if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_CN);
-        });
-    };
-    for (int it = 1; it < a.max_iter; it++) {
-        // keep the 16-bit-packed slot indices packed across iterations (unpacked they cost 2x the VGPRs)
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-            for (int i = 0; i < (WC + 1) / 2; i++)
-                if (!UNPACKED) asm volatile("" : "+v"(saddr[rr][i]));
-        bool bad[NF];
-#pragma unroll
-        for (int v = 0; v < NF; v++) bad[v] = false;
-        if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_VN);
-        vn_phase(bad);
-        if (HIST) flags_publish(bad, it);
-#ifdef QC_STAMPS
-        if (it == 20 && tid == 0) a.stamps[(size_t)wg * QC_STAMPS + 120] = __builtin_amdgcn_s_memtime(); // wave 0 reaches the VN barrier
-#endif
-        __syncthreads();
-#ifdef QC_STAMPS
-        stamp(__builtin_amdgcn_s_memtime());
-#endif
-        if (USE_PRIO) __builtin_amdgcn_s_setprio(QC_PRIO_CN);
-        if (HIST) {
-            (void)flags_collect(it);
-            if (a.per_frame && retire(it)) break;
-        }
-
-        // CN phase (LDPC_Decoder.cu:279-314)
-        {
-            constexpr bool ROWU = (Z % 64 == 0) && WC >= 4; // rows, hence their weights, are wave-uniform: a scalar branch picks the body
-            if constexpr (ROWU) {
-                int wu = 0;
-#pragma unroll
-                for (int rr = 0; rr < RPT; rr++) wu = max(wu, __builtin_amdgcn_readfirstlane(wrv[rr]));
-                if (wu <= WC - 2) cn_rows(std::integral_constant<int, WC - 2>{});
-                else if (wu == WC - 1) cn_rows(std::integral_constant<int, WC - 1>{});
-                else cn_rows(std::integral_constant<int, WC>{});
-            } else {
-                cn_rows(std::integral_constant<int, WC>{});
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef QC_STAMPS
-        if (it == 20 && tid == 0) a.stamps[(size_t)wg * QC_STAMPS + 121] = __builtin_amdgcn_s_memtime(); // wave 0 reaches the CN barrier
-#endif
-        __syncthreads();
-#ifdef QC_STAMPS
-        stamp(__builtin_amdgcn_s_memtime());
-#endif
-    }
-
-    // ---- final iteration: VN only (the CN pass after it is unobservable), then outputs -----------
-    int flag = 0;
-    if (!(HIST && done == ALL)) {
-        bool bad[NF];
-#pragma unroll
-        for (int v = 0; v < NF; v++) bad[v] = false;
-        vn_phase(bad);
-        emit(~done, bad);
-        flags_publish(bad, a.max_iter);
-        __syncthreads();
-        flag = flags_collect(a.max_iter);
-    }
-#ifdef QC_STAMPS
-    stamp(__builtin_amdgcn_s_memtime());
-#endif
-    if (tid < NF && f0 + tid < F) {
-        const bool stopped = HIST && ((done >> tid) & 1u);
-        a.D[(size_t)L * Z * F + f0 + tid] = stopped ? 1 : flag;
-        if (HIST && a.hist) a.hist[f0 + tid] = hist;
-        if (HIST && a.per_frame && !stopped) a.iters[f0 + tid] = a.max_iter;
-    }
-}
+#define QC1_NAME k_qc
+#define QC1_PERSIST 0
+#include "bldpc_qc1_body.inc"
+#undef QC1_NAME
+#undef QC1_PERSIST
+#define QC1_NAME k_qcp
+#define QC1_PERSIST 1
+#include "bldpc_qc1_body.inc"
+#undef QC1_NAME
+#undef QC1_PERSIST
 
 // ---------------------------------------------------------------------------------------------
 // Split-row variant: each check row is shared by the two half-waves of one wave (lanes i and i+32 own the
@@ -818,7 +523,7 @@ inline const QcVariant *qc_variants(int *count)
 #define X(NF, J, L, Z, WC, WV, G, MINW)                                                                  \
     {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW>::TPB,                              \
      QcGeom<NF, J, L, Z, WC, WV, G, MINW>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, false>,    \
-     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>, "row", 0, 0, 0},
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>, "row", 0, 0, 0, k_qcp<QcGeom<NF, J, L, Z, WC, WV, G, MINW>, true>},
 #define X2(NF, J, L, Z, WC, WV, GJ, MINW)                                                                 \
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::TPB,                            \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, false>, \
