@@ -536,7 +536,7 @@ inline const QcVariant *qc_variants(int *count)
      k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1},
 #define XR2(J, L, Z, TPB, WCS, YB, NG) /* CPT carries NG here */                                              \
     {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, false>,                    \
-     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true>, "regstate-halo", 0, NG, 2},
+     k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true>, "regstate-halo", 0, NG, 2, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true, true>},
     static const QcVariant v[] = {
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
@@ -814,11 +814,11 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, generic ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
     CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_hist, hipFuncAttributeMaxDynamicSharedMemorySize, generic ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
     if (v.fn_pf) {
-        CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_pf, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes), BLDPC_EHIP);
+        CLDPC_HIP(hipFuncSetAttribute((const void *)v.fn_pf, hipFuncAttributeMaxDynamicSharedMemorySize, generic ? (int)kLdsBytes : v.lds_bytes), BLDPC_EHIP);
         int occ = 0, dev = 0, ncu = 0;
         CLDPC_HIP(hipGetDevice(&dev), BLDPC_EHIP);
         CLDPC_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev), BLDPC_EHIP);
-        CLDPC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)v.fn_pf, v.threads, (size_t)v.lds_bytes + 16), BLDPC_EHIP);
+        CLDPC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)v.fn_pf, v.threads, (size_t)q->lds_bytes), BLDPC_EHIP);
         q->persist_grid = std::max(8, ncu * std::max(1, occ) / 8 * 8);
     }
     q->frames_per_wg = v.NF;

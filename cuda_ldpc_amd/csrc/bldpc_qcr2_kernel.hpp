@@ -267,21 +267,32 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
 }
 
 // LDS: S float[L][Z + 64] | 64 x +inf | flags.
-template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_qcr2(QcArgs a)
+// PERSIST (per-frame exit only): the grid fills the chip once and a workgroup takes frame after frame of its XCD from the counter
+// a.work[xcd] -- frames leave after 1 ... max_iter iterations, and one workgroup per frame leaves the CUs far apart (see k_qc2p)
+template <typename GM, bool HIST, bool PERSIST = false> __global__ __launch_bounds__(GM::TPB) void k_qcr2(QcArgs a)
 {
     constexpr int Z = GM::Z, TPB = GM::TPB, ZR = GM::ZR, N = GM::L * Z;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
-    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (wg >= a.nWG) return;
+    int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (!PERSIST && wg >= a.nWG) return;
     const int F = a.F;
     const int tid = threadIdx.x;
-    const int f = wg; // one frame per workgroup
-    const float *yf = a.y + (size_t)f * N;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(yf), 0, N * 4, 0x00020000);
     int *lds_flag = reinterpret_cast<int *>(lds + GM::FLAG_BASE);
     const bool zlast = !GM::RAGGED || (tid + (ZR - 1) * TPB < Z); // wave-uniform: this wave covers the last tile too
     auto s_byte = [&](int v) -> int { return (v + (v / Z) * 64) * 4; }; // (column * (Z + 64) + position) * 4
+    for (;;) { // (one pass unless PERSIST)
+    if (PERSIST) {
+        const int xcd = (int)(blockIdx.x & 7);
+        if (tid == 0) lds_flag[2] = atomicAdd(&a.work[xcd], 1);
+        __syncthreads();
+        const int ord = __builtin_amdgcn_readfirstlane(lds_flag[2]);
+        if (ord >= chunk || xcd * chunk + ord >= a.nWG) break;
+        wg = xcd * chunk + ord;
+    }
+    const int f = wg; // one frame per workgroup
+    const float *yf = a.y + (size_t)f * N;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(yf), 0, N * 4, 0x00020000);
 
     int bad = 0;
     for (int v = tid; v < N; v += TPB) { // iteration 1: S = (0 + 0 + ...) + y
@@ -342,4 +353,7 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
         if (HIST && a.hist) a.hist[f] = hist;
         if (HIST && a.per_frame) a.iters[f] = last;
     }
+    if (!PERSIST) break;
+    __syncthreads(); // S, the flags and the frame word are reused by the next frame
+    } // next frame
 }
