@@ -533,7 +533,7 @@ inline const QcVariant *qc_variants(int *count)
      k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0},
 #define XR(J, L, Z, TPB, WCS, MINW, YB)                                                                     \
     {1, J, L, Z, WCS, 31, 0, MINW, TPB, 0, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, false>,               \
-     k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1},
+     k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true, true>},
 #define XR2(J, L, Z, TPB, WCS, YB, NG) /* CPT carries NG here */                                              \
     {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, false>,                    \
      k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true>, "regstate-halo", 0, NG, 2, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true, true>},

@@ -243,22 +243,32 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
 }
 
 // LDS: S float[N] | flag.
-template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_qcr(QcArgs a)
+// PERSIST (per-frame exit only): frames of this XCD from the counter a.work[xcd], see k_qcr2 / k_qc2p
+template <typename GM, bool HIST, bool PERSIST = false> __global__ __launch_bounds__(GM::TPB) void k_qcr(QcArgs a)
 {
     constexpr int Z = GM::Z, TPB = GM::TPB, ZR = GM::ZR, N = GM::L * Z;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
-    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (wg >= a.nWG) return;
+    int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (!PERSIST && wg >= a.nWG) return;
     const int F = a.F;
     const int tid = threadIdx.x;
+    int *lds_flag = reinterpret_cast<int *>(lds + N * 4);
+    const bool zlast = !GM::RAGGED || (tid + (ZR - 1) * TPB < Z); // wave-uniform: this wave covers the last tile too
+    for (;;) { // (one pass unless PERSIST)
+    if (PERSIST) {
+        const int xcd = (int)(blockIdx.x & 7);
+        if (tid == 0) lds_flag[2] = atomicAdd(&a.work[xcd], 1);
+        __syncthreads();
+        const int ord = __builtin_amdgcn_readfirstlane(lds_flag[2]);
+        if (ord >= chunk || xcd * chunk + ord >= a.nWG) break;
+        wg = xcd * chunk + ord;
+    }
     const int f = wg; // one frame per workgroup
     const float *yf = a.y + (size_t)f * N;
     // the frame's channel values as a buffer resource: loads take one VGPR offset (4 tid) plus a scalar offset, instead
     // of a 64-bit address pair per load
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(yf), 0, N * 4, 0x00020000);
-    int *lds_flag = reinterpret_cast<int *>(lds + N * 4);
-    const bool zlast = !GM::RAGGED || (tid + (ZR - 1) * TPB < Z); // wave-uniform: this wave covers the last tile too
 
     int bad = 0;
     for (int v = tid; v < N; v += TPB) { // iteration 1: S = (0 + 0 + ...) + y
@@ -314,5 +324,8 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
         if (HIST && a.hist) a.hist[f] = hist;
         if (HIST && a.per_frame) a.iters[f] = last;
     }
+    if (!PERSIST) break;
+    __syncthreads(); // S, the flags and the frame word are reused by the next frame
+    } // next frame
 }
 
