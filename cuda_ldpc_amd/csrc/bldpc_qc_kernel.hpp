@@ -935,7 +935,7 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     int r;
     int run = max_iter;
     if (!q->ran_to_max) {
-        r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false);
+        r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false, (int *)and_ws);
         if (r) return r;
         int m = 0;
         CLDPC_HIP(hipMemsetAsync(and_ws, 0, sizeof(unsigned long long), st), BLDPC_EHIP);
