@@ -88,7 +88,32 @@ def cpu_baseline(name, J, L, Z, snr, iters, y_block, nframes):
                       % (nframes, iters, dt)}
 
 
-def pmc_onchip(kernel_name, kern_ms):
+def onchip_ceiling(kernel_name, cycles_per_launch, frames, iters):
+    """What actually bounds the fused kernels: the load of the VALU and of the LDS pipe per CU-iteration (one flooding
+    iteration of the frames a CU holds at a time), from the committed micro-benchmarks (profiles/onchip_model.json names the
+    rates and the instruction mix per kernel), against the cycles the kernel really takes: GRBM_GUI_ACTIVE / 8 per launch from
+    the committed SQ pass, over (frames / frames-per-CU / 256 CUs) * iters CU-iterations -- prologue, epilogue and the tail of
+    the launch included.  frac = the slower pipe's load / measured: 1.0 would be a kernel that does nothing but feed that pipe."""
+    try:
+        models = json.load(open(os.path.join(ROOT, "profiles", "onchip_model.json")))
+    except Exception:
+        return None
+    for key, m in models.items():
+        if not kernel_name.startswith(key) or not frames or not iters:
+            continue
+        cu_iters = frames / m["frames_per_cu"] / 256.0 * iters
+        measured = cycles_per_launch / cu_iters
+        pipe = max(m["valu_cycles_per_cu_iter"], m["lds_cycles_per_cu_iter"])
+        out = {"valu_cycles_per_cu_iter": m["valu_cycles_per_cu_iter"], "lds_cycles_per_cu_iter": m["lds_cycles_per_cu_iter"],
+               "measured_cycles_per_cu_iter": measured, "frac": pipe / measured, "model_source": m["source"]}
+        if m.get("loop_cycles_per_cu_iter_stamps"):  # the iteration loop alone, from in-kernel time stamps (no prologue / tail)
+            out["loop_cycles_per_cu_iter_stamps"] = m["loop_cycles_per_cu_iter_stamps"]
+            out["frac_of_loop"] = pipe / m["loop_cycles_per_cu_iter_stamps"]
+        return out
+    return None
+
+
+def pmc_onchip(kernel_name, kern_ms, frames=0, iters=0):
     """On-chip picture of the dominant kernel, looked up in the committed SQ counter passes (profiles/*_pmc.json "sq") --
     NOT measured in this run; "source" names the file.  The fused kernels are bound by VALU issue and the LDS pipe, not by
     HBM.  Reported: the wave-cycle split the guide defines (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, with
@@ -113,6 +138,7 @@ def pmc_onchip(kernel_name, kern_ms):
         return {"wave_cycle_split": split, "valu_instructions_per_simd_cycle": sq["SQ_INSTS_VALU"] / 1024.0 / cycles,
                 "lds_instructions_per_cu_cycle": (sq["SQ_INSTS_LDS"] / 256.0 / cycles) if sq.get("SQ_INSTS_LDS") else None,
                 "lds_array_util": sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles, "lds_bank_conflict_cycles": sq.get("SQ_LDS_BANK_CONFLICT"),
+                "ceiling": onchip_ceiling(kernel_name, cycles, frames, iters),
                 "source": "committed profile " + os.path.basename(p),
                 "note": "profiled pass of an earlier run of this command, not this run; kernel cycles from %s" % ("GRBM_GUI_ACTIVE/8" if sq.get("GRBM_GUI_ACTIVE") else "avg_ms * 2.3 GHz")}
     return None
@@ -326,6 +352,8 @@ def main():
     for _ in range(args.warmup):
         step()
     SIM._dev.zero_()
+    torch.cuda.synchronize(dev)
+    code.kernel_ms_mean()  # drop the warm-up pairs
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -333,8 +361,6 @@ def main():
         ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
         C.Decode_Statistic(code, y, SIM._dev, max_iter=iters, exit_mode=C.EXIT_FIXED, kernel=kernel, D=D, stream=stream)
         ev[k][1].record(stream)
-        if k == args.steps - 1:
-            dom_ms_last = code.last_kernel_ms()  # dominant kernel alone (events recorded inside bldpc_decode)
     counters = SIM._dev.clone()
     if world > 1:
         dist.all_reduce(counters)  # the only collective: 5 int64 error counters
@@ -345,7 +371,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     call_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # whole bldpc_decode call (regroup + decode + unpack)
-    kern_ms = dom_ms_last
+    # dominant kernel alone: every timed step recorded its own event pair inside bldpc_decode (on the kernel's stream); the mean
+    # over ALL timed steps (the library keeps the last 64 pairs), queried after the timed region so that nothing synchronises in it
+    kern_ms, kern_n = code.kernel_ms_mean()
 
     if rank == 0:
         total_cw = frames * world * args.steps
@@ -369,9 +397,10 @@ def main():
                        "kernel": code.last_kernel, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(code.last_kernel)[0], "traffic_source": pmc_traffic(code.last_kernel)[1],
-                         "kernel": code.last_kernel, "kernel_ms": kern_ms, "decode_call_ms": call_ms,
+                         "kernel": code.last_kernel, "kernel_ms": kern_ms, "kernel_ms_launches_averaged": kern_n, "decode_call_ms": call_ms,
                          "achieved_decode_call": alg_bytes / (call_ms * 1e-3) / 1e9,  # the whole bldpc_decode_statistic call: (regroup +) decode + unpack with the error counts + the counters
-                         "algorithmic_bytes_per_launch": alg_bytes, "model": model, "onchip": pmc_onchip(code.last_kernel, kern_ms)},
+                         "algorithmic_bytes_per_launch": alg_bytes, "model": model,
+                         "onchip": pmc_onchip(code.last_kernel, kern_ms, frames=frames, iters=iters)},
             "stats": {"frames": frames * world * args.steps, "error_frames": c[0], "error_bits": c[1],
                       "FER": c[0] / (frames * world * args.steps), "BER": c[1] / (frames * world * args.steps) / code.K},
         }

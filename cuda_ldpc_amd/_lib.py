@@ -40,6 +40,7 @@ lib.bldpc_statistic_per_frame.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c
 lib.bldpc_decode_statistic.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
 lib.bldpc_set_profiling.argtypes = [c_void_p, c_int]
 lib.bldpc_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_float)]
+lib.bldpc_kernel_ms_mean.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_int)]
 lib.bldpc_awgn_channel_host.argtypes = [c_void_p, ctypes.c_float, c_void_p, c_void_p, c_int, c_int]
 lib.bldpc_awgn_channel_device.argtypes = [c_void_p, ctypes.c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]
 lib.bldpc_sigma.restype = ctypes.c_float

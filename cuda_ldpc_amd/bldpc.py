@@ -25,6 +25,22 @@ def _dev_ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _check_D(D, N, F, dev):
+    """A caller-supplied D goes to the C ABI as a raw pointer: a wrong shape is an out-of-bounds device write and a
+    misaligned one faults in the 16-byte stores of the unpack kernel -- refuse both here."""
+    if not (torch.is_tensor(D) and D.is_cuda and D.device == dev and D.dtype == torch.int32 and D.is_contiguous()
+            and D.dim() == 2 and tuple(D.shape) == (N + 1, F)):
+        raise ValueError("D must be a contiguous CUDA int32 tensor [N+1=%d, F=%d] on %s" % (N + 1, F, dev))
+    if D.data_ptr() % 16:
+        raise ValueError("D must be 16-byte aligned")
+
+
+def _check_counters(counters, n, dev):
+    if not (torch.is_tensor(counters) and counters.is_cuda and counters.device == dev and counters.dtype == torch.int64
+            and counters.is_contiguous() and counters.numel() >= n):
+        raise ValueError("counters must be a contiguous CUDA int64 tensor of at least %d elements on %s" % (n, dev))
+
+
 def Get_H(path, J, L):
     """Get_H (Simulation.cu:292-354): -> (H[J*L], Weight_Checknode[J+1], Weight_Variablenode[L+1]) int32 host arrays."""
     H = np.zeros(J * L, np.int32)
@@ -123,6 +139,13 @@ class BinaryCode:
         check(lib.bldpc_last_kernel_ms(self._h, ctypes.byref(ms)), "bldpc_last_kernel_ms")
         return ms.value
 
+    def kernel_ms_mean(self):
+        """(mean ms of the dominant kernel, calls averaged) over the profiled decode calls since the last query -- every call
+        records its own event pair, nothing synchronises in between (bldpc_kernel_ms_mean)."""
+        ms, n = ctypes.c_float(0), ctypes.c_int(0)
+        check(lib.bldpc_kernel_ms_mean(self._h, ctypes.byref(ms), ctypes.byref(n)), "bldpc_kernel_ms_mean")
+        return ms.value, n.value
+
     def close(self):
         if self._h:
             lib.bldpc_code_destroy(self._h)
@@ -153,6 +176,8 @@ def LDPC_Decoder_GPU(code, Channel_Out, max_iter=50, length=0, exit_mode=EXIT_BA
     dev = Channel_Out.device
     if D is None:
         D = torch.empty((code.N + 1, F), dtype=torch.int32, device=dev)
+    else:
+        _check_D(D, code.N, F, dev)
     app = torch.empty((code.N, F), dtype=torch.float32, device=dev) if want_app else None
     hist = torch.zeros(F, dtype=torch.int64, device=dev) if want_flag_hist else None
     it = ctypes.c_int(0)
@@ -180,8 +205,11 @@ def Decode_Statistic(code, Channel_Out, counters, max_iter=50, length=0, exit_mo
         raise ValueError("Channel_Out must be [N=%d, F]" % code.N)
     F = int(Channel_Out.shape[1])
     dev = Channel_Out.device
+    _check_counters(counters, 5, dev)
     if D is None:
         D = torch.empty((code.N + 1, F), dtype=torch.int32, device=dev)
+    else:
+        _check_D(D, code.N, F, dev)
     iters = torch.empty(F, dtype=torch.int32, device=dev) if exit_mode == EXIT_PER_FRAME else None
     it = ctypes.c_int(0)
     st = ctypes.c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)

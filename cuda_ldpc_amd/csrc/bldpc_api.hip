@@ -30,6 +30,11 @@ struct bldpc_code {
     QcPlan qc;            // fused LDS kernel description (frames_per_wg == 0: unavailable)
     const char *last_kernel = "none";
     bool profiling = false;
+    // profiling: a ring of event pairs, one pair per decode call, so that a bench can average the dominant kernel over ALL of its
+    // timed steps without synchronising after each (bldpc_kernel_ms_mean); ev0/ev1 point at the pair of the call in progress
+    static constexpr unsigned kEvRing = 64;
+    hipEvent_t evr[2 * kEvRing] = {};
+    unsigned ev_n = 0; // decode calls recorded since the last bldpc_kernel_ms_mean
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -209,8 +214,8 @@ extern "C" int bldpc_code_destroy(bldpc_code *c)
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     c->rq.release(); c->bad.release(); c->cnt.release(); c->bits.release(); c->yg.release(); c->errs.release(); c->itw.release();
     qc_plan_release(&c->qc);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->evr)
+        if (e) (void)hipEventDestroy(e);
     delete c;
     return BLDPC_OK;
 }
@@ -228,11 +233,30 @@ extern "C" const char *bldpc_last_kernel(const bldpc_code *c) { return c ? c->la
 extern "C" int bldpc_set_profiling(bldpc_code *c, int enable)
 {
     if (!c) return fail(BLDPC_EINVAL, "bldpc_set_profiling: null code");
-    if (enable && !c->ev0) {
-        CLDPC_HIP(hipEventCreate(&c->ev0), BLDPC_EHIP);
-        CLDPC_HIP(hipEventCreate(&c->ev1), BLDPC_EHIP);
+    if (enable && !c->evr[0]) {
+        for (unsigned i = 0; i < 2 * bldpc_code::kEvRing; i++) CLDPC_HIP(hipEventCreate(&c->evr[i]), BLDPC_EHIP);
     }
     c->profiling = enable != 0;
+    c->ev_n = 0;
+    c->ev0 = c->ev1 = nullptr;
+    return BLDPC_OK;
+}
+
+extern "C" int bldpc_kernel_ms_mean(bldpc_code *c, float *mean_ms, int *launches)
+{
+    if (!c || !mean_ms || !c->evr[0] || !c->ev_n) return fail(BLDPC_EINVAL, "bldpc_kernel_ms_mean: no profiled decode call since the last one");
+    const unsigned n = std::min(c->ev_n, bldpc_code::kEvRing);
+    double sum = 0;
+    for (unsigned k = 0; k < n; k++) {
+        const unsigned slot = (c->ev_n - 1 - k) % bldpc_code::kEvRing;
+        float ms = 0;
+        CLDPC_HIP(hipEventSynchronize(c->evr[2 * slot + 1]), BLDPC_EHIP);
+        CLDPC_HIP(hipEventElapsedTime(&ms, c->evr[2 * slot], c->evr[2 * slot + 1]), BLDPC_EHIP);
+        sum += ms;
+    }
+    *mean_ms = (float)(sum / n);
+    if (launches) *launches = (int)n;
+    c->ev_n = 0;
     return BLDPC_OK;
 }
 
@@ -296,7 +320,7 @@ static int run_table(bldpc_code *c, const float *y, int F, int max_iter, int len
 }
 
 static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int length, int exit_mode, int kernel, int *D, float *app,
-                       unsigned long long *flag_hist, int *itera, int *iters, void *stream)
+                       unsigned long long *flag_hist, int *itera, int *iters, void *stream, QcStat *stat = nullptr)
 {
     if (!c || !y || !D || !itera) return fail(BLDPC_EINVAL, "bldpc_decode: null argument");
     if (F <= 0 || max_iter <= 0) return fail(BLDPC_EINVAL, "bldpc_decode: F=%d max_iter=%d must be positive", F, max_iter);
@@ -305,6 +329,11 @@ static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int l
     if (exit_mode != BLDPC_EXIT_FIXED && exit_mode != BLDPC_EXIT_BATCH_GLOBAL && exit_mode != BLDPC_EXIT_PER_FRAME)
         return fail(BLDPC_EINVAL, "unknown exit_mode %d", exit_mode);
     hipStream_t st = (hipStream_t)stream;
+    if (c->profiling) { // this call's event pair
+        const unsigned slot = c->ev_n++ % bldpc_code::kEvRing;
+        c->ev0 = c->evr[2 * slot];
+        c->ev1 = c->evr[2 * slot + 1];
+    }
     const bool qc_ok = c->has_qc && c->qc.frames_per_wg > 0;
     // The fused kernels keep a frame's flag history in one 64-bit word: the reference's batch-global rule (which is found
     // from the histories) and a requested flag_hist need max_iter <= 64 there.  The reference takes any maxIT, and so do the
@@ -325,7 +354,7 @@ static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int l
         if (exit_mode == BLDPC_EXIT_BATCH_GLOBAL) CLDPC_HIP(c->itw.reserve((size_t)F * sizeof(int)), BLDPC_ENOMEM);
         int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
                           (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, iters, (int *)c->itw.p, st,
-                          c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr);
+                          c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr, stat);
         c->last_kernel = c->qc.name;
         return r;
     }
@@ -400,20 +429,22 @@ extern "C" int bldpc_decode_statistic(bldpc_code *c, const float *y, int F, int 
     const int slen = length == 0 ? c->K : length;
     hipStream_t st = (hipStream_t)stream;
     const bool single = exit_mode == BLDPC_EXIT_FIXED || exit_mode == BLDPC_EXIT_PER_FRAME;
+    QcStat stat; // per call: nothing of this lives in the shared code object
     if (single && c->has_qc && slen >= 0 && slen <= c->N) {
         if ((size_t)F * sizeof(int) > c->errs.cap) {
             CLDPC_HIP(c->errs.reserve((size_t)F * sizeof(int)), BLDPC_ENOMEM);
             CLDPC_HIP(hipMemsetAsync(c->errs.p, 0, (size_t)F * sizeof(int), st), BLDPC_EHIP);
         }
-        c->qc.stat_errs = (int *)c->errs.p;
-        c->qc.stat_length = slen;
+        stat.errs = (int *)c->errs.p;
+        stat.length = slen;
     }
-    c->qc.stat_done = false;
-    const int r = decode_impl(c, y, F, max_iter, length, exit_mode, kernel, D, nullptr, nullptr, itera, iters, stream);
-    const bool fused = c->qc.stat_done;
-    c->qc.stat_errs = nullptr;
-    c->qc.stat_done = false;
-    if (r) return r;
+    const int r = decode_impl(c, y, F, max_iter, length, exit_mode, kernel, D, nullptr, nullptr, itera, iters, stream, &stat);
+    const bool fused = stat.done;
+    if (r) {
+        // the unpack pass may have accumulated into errs before the failure: k_stat_final, which re-zeroes it, will not run
+        if (fused) (void)hipMemsetAsync(c->errs.p, 0, (size_t)F * sizeof(int), st);
+        return r;
+    }
     if (!fused) return statistic_impl(c, D, nullptr, F, length, *itera, iters, counters, stream);
     hipLaunchKernelGGL(k_stat_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, (int *)c->errs.p, D + (size_t)c->N * F, F, *itera,
                        iters, counters);

@@ -595,11 +595,17 @@ struct QcPlan {
     char name[96] = "qc_lds(unavailable)";
     mutable int ran_to_max = 0; // BATCH_GLOBAL: the previous batch did not stop before max_iter (a performance hint, never a result)
     int persist_grid = 0; // k_qc2p: workgroups that fill the chip once (a multiple of 8)
-    mutable bool y_in_place = false; // this decode call hands the kernels the caller's [N][F] array itself (qc_decode)
-    // bldpc_decode_statistic: per-frame error counts wanted from the pass that unpacks the hard bits (single-launch modes only)
-    mutable int *stat_errs = nullptr;
-    mutable int stat_length = 0;
-    mutable bool stat_done = false;
+    // experiment / test switches, read ONCE when the plan is built (never per decode call):
+    bool no_persist = false;    // BLDPC_NO_PERSIST: one workgroup per frame group even where the persistent form exists
+    bool force_regroup = false; // BLDPC_REGROUP: k_regroup_y in front of the row / half-row kernels instead of reading in place
+};
+
+// bldpc_decode_statistic: per-frame error counts wanted from the pass that unpacks the hard bits (single-launch modes only).
+// Per CALL state (it used to live in the plan, where a concurrent decode on another host thread could pick it up).
+struct QcStat {
+    int *errs = nullptr; // device int32 [F], all zero on entry
+    int length = 0;
+    bool done = false;   // set when the unpack pass has accumulated into errs
 };
 
 inline void qc_plan_release(QcPlan *q)
@@ -642,6 +648,9 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     int nvar = 0;
     const QcVariant *vars = qc_variants(&nvar);
     const char *pin = getenv("BLDPC_QC_VARIANT");
+    const bool no_halo = getenv("BLDPC_NO_HALO") != nullptr; // tests: k_qcr on a code k_qcr2 takes
+    q->no_persist = getenv("BLDPC_NO_PERSIST") != nullptr;
+    q->force_regroup = getenv("BLDPC_REGROUP") != nullptr;
     // k_qcr2 gives per-lane addresses to two slots per (block row, tile): no more than two of a row's blocks may wrap past Z in
     // the same tile of 64 circulant positions (shifts taken relative to the register-resident column, as the kernel sees them)
     auto qcr2_fits = [&](int ng) -> bool {
@@ -666,7 +675,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         const QcVariant &v = vars[vi];
         if (pin && atoi(pin) != vi) continue;
         if (v.regstate) { // register-state kernel
-            if (v.regstate == 2 && (!qcr2_fits(v.CPT) || getenv("BLDPC_NO_HALO"))) continue; // three blocks of one row wrap in the same tile: k_qcr takes the code (env: tests)
+            if (v.regstate == 2 && (!qcr2_fits(v.CPT) || no_halo)) continue; // three blocks of one row wrap in the same tile: k_qcr takes the code (env: tests)
             const size_t lds = v.regstate == 2 ? (size_t)L * (Z + 64) * 4 + 272 : (size_t)L * Z * 4 + 16;
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.MINW > Wcmin || L > 255 || Z > 2047 || lds > kLdsBytes) continue;
             q->lds_bytes = (int)lds;
@@ -849,12 +858,12 @@ inline int qc_regroup(const QcPlan *q, const float *y, float *yg, int F, hipStre
 // y here is the regrouped buffer produced by qc_regroup.
 inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int length, int *D, float *app,
                      unsigned long long *hist, unsigned *bits, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                     int *iters = nullptr, bool expand = true, int *work = nullptr)
+                     int *iters = nullptr, bool expand = true, int *work = nullptr, QcStat *stat = nullptr, bool y_in_place = false)
 {
     int nvar = 0;
     const QcVariant &v = qc_variants(&nvar)[q->variant];
     QcArgs a;
-    a.y = y; a.y_raw = q->y_in_place ? y : nullptr; a.D = D; a.bits = bits; a.app = app; a.hist = hist;
+    a.y = y; a.y_raw = y_in_place ? y : nullptr; a.D = D; a.bits = bits; a.app = app; a.hist = hist;
     a.per_frame = (iters && hist) ? 1 : 0; a.iters = iters; // per-frame exit lives in the flag-tracking instantiation
     a.cn_edges = q->d_cn; a.rowptr = q->d_rowptr; a.vn_edges = q->d_vn; a.wv = q->d_wv;
     a.F = F;
@@ -866,7 +875,7 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 #endif
     unsigned grid = (unsigned)((a.nWG + 7) / 8 * 8);
     QcKernel fn = hist ? v.fn_hist : v.fn;
-    if (a.per_frame && v.fn_pf && work && q->persist_grid > 0 && grid > (unsigned)q->persist_grid && !getenv("BLDPC_NO_PERSIST")) {
+    if (a.per_frame && v.fn_pf && work && q->persist_grid > 0 && grid > (unsigned)q->persist_grid && !q->no_persist) {
         // per-frame exit on the half-row kernel: persistent workgroups, one frame-pair counter per XCD (k_qc2p)
         CLDPC_HIP(hipMemsetAsync(work, 0, 8 * sizeof(int), st), BLDPC_EHIP);
         a.work = work;
@@ -878,9 +887,9 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
     if (ev1) (void)hipEventRecord(ev1, st);
     const int NW = q->L * q->Z / 32;
     if (expand) {
-        hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW, q->stat_errs,
-                           q->stat_length);
-        if (q->stat_errs) q->stat_done = true;
+        hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((F + 1023) / 1024), (unsigned)NW), dim3(256), 0, st, bits, D, F, NW, stat ? stat->errs : nullptr,
+                           stat ? stat->length : 0);
+        if (stat && stat->errs) stat->done = true;
     }
     CLDPC_HIP(hipGetLastError(), BLDPC_EHIP);
     return BLDPC_OK;
@@ -891,26 +900,25 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
                      unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, unsigned *bits,
                      float *yg, int *itera, int *iters, int *iters_ws, hipStream_t st, hipEvent_t ev0 = nullptr,
-                     hipEvent_t ev1 = nullptr)
+                     hipEvent_t ev1 = nullptr, QcStat *stat = nullptr)
 {
     // k_qc / k_qc2 carry two frames per lane: with F even (and the frame-fastest rows 8-byte aligned) a lane's pair of channel
     // values is 8 contiguous bytes of the reference's own layout and the kernels read it in place -- every 64-byte sector is
     // shared by the 4 workgroups of 8 neighbouring frames, which the XCD-aware block order puts on one L2 -- instead of paying a
     // separate pass that reads and writes the whole input (0.24 ms of a 5.9 ms step at config 2).
-    const bool in_place = qc_reads_in_place(q) && (F % 2 == 0) && ((uintptr_t)y % 8 == 0) && !getenv("BLDPC_REGROUP");
+    const bool in_place = qc_reads_in_place(q) && (F % 2 == 0) && ((uintptr_t)y % 8 == 0) && !q->force_regroup;
     if (!in_place) {
         int rr = qc_regroup(q, y, yg, F, st);
         if (rr) return rr;
         y = yg;
     }
-    q->y_in_place = in_place;
     if (exit_mode == BLDPC_EXIT_FIXED) {
         *itera = max_iter;
-        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, bits, st, ev0, ev1);
+        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist, bits, st, ev0, ev1, nullptr, true, nullptr, stat, in_place);
     }
     if (exit_mode == BLDPC_EXIT_PER_FRAME) { // every workgroup leaves when its own frames have stopped; nothing to wait for
         *itera = max_iter;
-        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters, true, (int *)and_ws);
+        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters, true, (int *)and_ws, stat, in_place);
     }
     // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are flagged.  No
     // workgroup can know that iteration while it runs, so it is found first and the batch then decoded with exactly that
@@ -935,7 +943,7 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     int r;
     int run = max_iter;
     if (!q->ran_to_max) {
-        r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false, (int *)and_ws);
+        r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false, (int *)and_ws, nullptr, in_place);
         if (r) return r;
         int m = 0;
         CLDPC_HIP(hipMemsetAsync(and_ws, 0, sizeof(unsigned long long), st), BLDPC_EHIP);
@@ -946,14 +954,14 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
         run = m;
     }
     for (;; run = std::min(max_iter, std::max(run + 4, 2 * run))) {
-        if ((r = qc_launch(q, y, F, run, length, D, app, hist, bits, st, ev0, ev1))) return r;
+        if ((r = qc_launch(q, y, F, run, length, D, app, hist, bits, st, ev0, ev1, nullptr, true, nullptr, nullptr, in_place))) return r;
         unsigned long long all = 0; // bit it-1: every frame flagged after iteration it
         if ((r = all_flagged(run, &all))) return r;
         if (all) {
             const int stop = __builtin_ctzll(all) + 1;
             *itera = stop;
             q->ran_to_max = (stop == max_iter);
-            return stop < run ? qc_launch(q, y, F, stop, length, D, app, flag_hist, bits, st, ev0, ev1) : BLDPC_OK;
+            return stop < run ? qc_launch(q, y, F, stop, length, D, app, flag_hist, bits, st, ev0, ev1, nullptr, true, nullptr, nullptr, in_place) : BLDPC_OK;
         }
         if (run == max_iter) {
             *itera = max_iter;

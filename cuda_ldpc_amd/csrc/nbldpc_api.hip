@@ -7,6 +7,7 @@
 #include "../../include/nbldpc.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +35,17 @@ struct nbldpc_code {
     int zero_coeff = 0; // an edge with coefficient 0 exists (EMS only, see nbldpc_code_create)
     int persist_grid = 0; // k_nb_ems / k_nb_ems_wide: workgroups that fill the chip once (CUs x workgroups per CU)
     bool hbm = false;   // decoded by k_nb_ems_hbm (state in a global-memory workspace): LDS too small or rows heavier than kNbMaxW
+    int tmm_grid[2] = {0, 0}; // k_nb_tmm<q, layered>: the same, per schedule (0 = flooding, 1 = layered), fixed at create time
+    bool no_persist = false;  // NBLDPC_NO_PERSIST, read once at create time (tests / experiments): one workgroup per frame
+    // Frame counters of the persistent kernels: a ring of kWorkSlots words, one per decode call in flight (the call zeroes its
+    // slot stream-ordered before the launch), instead of a hipMallocAsync / hipFreeAsync pair per call.  Calls on different
+    // streams never share a slot unless more than kWorkSlots calls on this code object are in flight at once.
+    int *d_work = nullptr;
+    std::atomic<unsigned> work_next{0};
 };
+constexpr unsigned kWorkSlots = 1024, kWorkStride = 16; // 64 bytes apart: one counter per cache line
+
+static int *next_work_slot(nbldpc_code *c) { return c->d_work + (size_t)(c->work_next.fetch_add(1) % kWorkSlots) * kWorkStride; }
 
 extern "C" const char *nbldpc_last_error(void) { return err_buf(); }
 
@@ -127,6 +138,14 @@ static int up(void **dst, const void *src, size_t bytes)
     CLDPC_HIP(hipMalloc(dst, bytes), NBLDPC_ENOMEM);
     CLDPC_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), NBLDPC_EHIP);
     return NBLDPC_OK;
+}
+
+using TmmKernel = void (*)(TmmArgs);
+static TmmKernel tmm_kernel(int q, bool layered)
+{
+    if (q == 64) return layered ? k_nb_tmm<64, true> : k_nb_tmm<64, false>;
+    if (q == 32) return layered ? k_nb_tmm<32, true> : k_nb_tmm<32, false>;
+    return layered ? k_nb_tmm<16, true> : k_nb_tmm<16, false>;
 }
 
 using NbKernel = void (*)(NbArgs);
@@ -253,14 +272,28 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         if (hbm) e = hipFuncSetAttribute((const void *)k_nb_ems_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256); // GF(256) table
         else e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        if (!r && !hbm) {
-            int occ = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)nb_kernel(q, dv), nb_threads(q), lds) == hipSuccess && occ > 0)
-                c->persist_grid = prop.multiProcessorCount * occ;
+        int dev = 0, ncu = 0;
+        const bool have_cu = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+        if (!r && !hbm && have_cu) {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)nb_kernel(q, dv), nb_threads(q), lds) == hipSuccess && occ > 0)
+                c->persist_grid = ncu * occ;
+        }
+        for (int layered = 0; !r && c->tmm_ok && layered < 2; layered++) { // per-kernel attributes and grids once, not per decode call
+            const size_t tl = tmm_lds_bytes(N, M, q, dv, dc, layered != 0);
+            TmmKernel k = tmm_kernel(q, layered != 0);
+            e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); break; }
+            int occ = 0;
+            if (have_cu && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k, kTmmThreads, tl) == hipSuccess && occ > 0)
+                c->tmm_grid[layered] = ncu * occ;
+        }
+        if (!r) {
+            e = hipMalloc((void **)&c->d_work, (size_t)kWorkSlots * kWorkStride * sizeof(int));
+            if (e != hipSuccess) r = fail(NBLDPC_ENOMEM, "hipMalloc(frame counters): %s", hipGetErrorString(e));
         }
     }
+    c->no_persist = getenv("NBLDPC_NO_PERSIST") != nullptr;
     if (r) { nbldpc_code_destroy(c); return r; }
     *out = c;
     return NBLDPC_OK;
@@ -269,7 +302,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
 extern "C" int nbldpc_code_destroy(nbldpc_code *c)
 {
     if (!c) return NBLDPC_OK;
-    void *ptrs[] = {c->d_vn_w, c->d_vn_thr, c->d_vn_gf, c->d_cn_w, c->d_cn_src, c->d_cn_gf, c->d_cn_vn, c->d_mul, c->d_cn_hinv, c->d_row_order, c->d_level_begin};
+    void *ptrs[] = {c->d_vn_w, c->d_vn_thr, c->d_vn_gf, c->d_cn_w, c->d_cn_src, c->d_cn_gf, c->d_cn_vn, c->d_mul, c->d_cn_hinv, c->d_row_order, c->d_level_begin, c->d_work};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -296,10 +329,10 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         const size_t cap = std::max<size_t>(1, ((size_t)2 << 30) / (slot * sizeof(float)));
         const int slots = (int)std::min<size_t>({(size_t)B, (size_t)1024, cap});
         void *ws = nullptr;
-        CLDPC_HIP(hipMallocAsync(&ws, (size_t)slots * slot * sizeof(float) + 64, st), NBLDPC_ENOMEM);
+        CLDPC_HIP(hipMallocAsync(&ws, (size_t)slots * slot * sizeof(float), st), NBLDPC_ENOMEM);
         a.ws = (float *)ws;
         a.ws_stride = slot;
-        a.work = (int *)((char *)ws + (size_t)slots * slot * sizeof(float)); // frame counter behind the slots
+        a.work = next_work_slot(c);
         CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
         hipLaunchKernelGGL(k_nb_ems_hbm, dim3(slots), dim3(kNbHbmThreads), (size_t)c->q * c->q, st, a);
         const hipError_t le = hipGetLastError();
@@ -307,29 +340,17 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         CLDPC_HIP(le, NBLDPC_EHIP);
         return NBLDPC_OK;
     }
-    if (c->persist_grid > 0 && B > c->persist_grid && !getenv("NBLDPC_NO_PERSIST")) { // (env: experiments)
-        // persistent workgroups and a frame counter (k_nb_ems): stream-ordered, so that calls on different streams do not share it
-        void *work = nullptr;
-        CLDPC_HIP(hipMallocAsync(&work, sizeof(int), st), NBLDPC_ENOMEM);
-        CLDPC_HIP(hipMemsetAsync(work, 0, sizeof(int), st), NBLDPC_EHIP);
-        a.work = (int *)work;
+    if (c->persist_grid > 0 && B > c->persist_grid && !c->no_persist) {
+        // persistent workgroups and a frame counter (k_nb_ems), zeroed stream-ordered; one ring slot per call in flight
+        a.work = next_work_slot(c);
+        CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
         hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(c->persist_grid), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
-        const hipError_t le = hipGetLastError();
-        CLDPC_HIP(hipFreeAsync(work, st), NBLDPC_EHIP);
-        CLDPC_HIP(le, NBLDPC_EHIP);
+        CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
         return NBLDPC_OK;
     }
     hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
-}
-
-using TmmKernel = void (*)(TmmArgs);
-static TmmKernel tmm_kernel(int q, bool layered)
-{
-    if (q == 64) return layered ? k_nb_tmm<64, true> : k_nb_tmm<64, false>;
-    if (q == 32) return layered ? k_nb_tmm<32, true> : k_nb_tmm<32, false>;
-    return layered ? k_nb_tmm<16, true> : k_nb_tmm<16, false>;
 }
 
 extern "C" int nbldpc_tmm_decode_batch(nbldpc_code *c, const float *Lch, int B, int layered, int maxIT, int *out, int *iters, int *ok,
@@ -345,20 +366,13 @@ extern "C" int nbldpc_tmm_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     a.N = c->N; a.M = c->M; a.q = c->q; a.dv = c->dv; a.dc = c->dc; a.B = B; a.max_iter = maxIT; a.levels = c->levels;
     const size_t lds = tmm_lds_bytes(c->N, c->M, c->q, c->dv, c->dc, layered != 0);
     TmmKernel k = tmm_kernel(c->q, layered != 0);
-    CLDPC_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), NBLDPC_EHIP);
     hipStream_t st = (hipStream_t)stream;
-    int occ = 0, dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k, kTmmThreads, lds) == hipSuccess && occ > 0 && B > ncu * occ &&
-        !getenv("NBLDPC_NO_PERSIST")) { // persistent workgroups and a frame counter, as in nbldpc_ems_decode_batch
-        void *work = nullptr;
-        CLDPC_HIP(hipMallocAsync(&work, sizeof(int), st), NBLDPC_ENOMEM);
-        CLDPC_HIP(hipMemsetAsync(work, 0, sizeof(int), st), NBLDPC_EHIP);
-        a.work = (int *)work;
-        hipLaunchKernelGGL(k, dim3(ncu * occ), dim3(kTmmThreads), lds, st, a);
-        const hipError_t le = hipGetLastError();
-        CLDPC_HIP(hipFreeAsync(work, st), NBLDPC_EHIP);
-        CLDPC_HIP(le, NBLDPC_EHIP);
+    const int pgrid = c->tmm_grid[layered != 0];
+    if (pgrid > 0 && B > pgrid && !c->no_persist) { // persistent workgroups and a frame counter, as in nbldpc_ems_decode_batch
+        a.work = next_work_slot(c);
+        CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
+        hipLaunchKernelGGL(k, dim3(pgrid), dim3(kTmmThreads), lds, st, a);
+        CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
         return NBLDPC_OK;
     }
     hipLaunchKernelGGL(k, dim3(B), dim3(kTmmThreads), lds, st, a);
@@ -368,20 +382,32 @@ extern "C" int nbldpc_tmm_decode_batch(nbldpc_code *c, const float *Lch, int B, 
 
 extern "C" int nbldpc_demodulate_bpsk(const nbldpc_code *c, const float *rx, float sigma, int B, float *Lch, void *stream)
 {
-    if (!c || !rx || !Lch || B <= 0 || !(sigma > 0)) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_bpsk: bad argument");
-    const size_t total = (size_t)B * c->N * (c->q - 1);
-    hipLaunchKernelGGL(k_nb_demod_bpsk, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rx, sigma, B, c->N, c->q,
-                       c->m, Lch);
+    if (!c) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_bpsk: bad argument");
+    return nbldpc_demodulate_bpsk_nq(c->N, c->q, rx, sigma, B, Lch, stream);
+}
+
+extern "C" int nbldpc_demodulate_bpsk_nq(int N, int q, const float *rx, float sigma, int B, float *Lch, void *stream)
+{
+    int m = 0;
+    while ((1 << m) < q) m++;
+    if (N <= 0 || q < 2 || (1 << m) != q || !rx || !Lch || B <= 0 || !(sigma > 0)) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_bpsk: bad argument");
+    const size_t total = (size_t)B * N * (q - 1);
+    hipLaunchKernelGGL(k_nb_demod_bpsk, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rx, sigma, B, N, q, m, Lch);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }
 
 extern "C" int nbldpc_demodulate_qam(const nbldpc_code *c, const float *rx, const float *con, float sigma, int B, float *Lch, void *stream)
 {
-    if (!c || !rx || !con || !Lch || B <= 0 || !(sigma > 0)) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_qam: bad argument");
-    const size_t total = (size_t)B * c->N * (c->q - 1);
-    hipLaunchKernelGGL(k_nb_demod_qam, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rx, con, sigma, B, c->N,
-                       c->q, Lch);
+    if (!c) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_qam: bad argument");
+    return nbldpc_demodulate_qam_nq(c->N, c->q, rx, con, sigma, B, Lch, stream);
+}
+
+extern "C" int nbldpc_demodulate_qam_nq(int N, int q, const float *rx, const float *con, float sigma, int B, float *Lch, void *stream)
+{
+    if (N <= 0 || q < 2 || !rx || !con || !Lch || B <= 0 || !(sigma > 0)) return fail(NBLDPC_EINVAL, "nbldpc_demodulate_qam: bad argument");
+    const size_t total = (size_t)B * N * (q - 1);
+    hipLaunchKernelGGL(k_nb_demod_qam, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rx, con, sigma, B, N, q, Lch);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }
@@ -428,6 +454,8 @@ inline float random_module(int *seed) // src/LDPC_Encoder.cpp:70-79
     return t;
 }
 } // namespace
+
+extern "C" float nbldpc_random_module(int seed[3]) { return random_module(seed); }
 
 extern "C" int nbldpc_awgn_channel_host(int seed[3], float sigma, const int *cw, int N, int m, float *rx)
 {
@@ -566,6 +594,102 @@ extern "C" int nbldpc_awgn_channel_device_qam(int seed[3], float sigma, const in
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     const unsigned long long draws = 4ull * (unsigned long long)N * B;
     for (int i = 0; i < 3; i++) seed[i] = (int)(((unsigned long long)seed[i] * nb_powmod(kNbA[i], draws, kNbM[i])) % kNbM[i]);
+    return NBLDPC_OK;
+}
+
+// ---- the reference's AWGNChannel_CPU as it is declared: noise on a modulated frame (any constellation) -------------------------
+
+extern "C" int nbldpc_awgn_channel_host_sym(int seed[3], float sigma, const float *tx, int len, float *rx)
+{
+    if (!seed || !tx || !rx || len <= 0) return fail(NBLDPC_EINVAL, "nbldpc_awgn_channel_host_sym: bad argument");
+    const double two_pi = 2 * 3.1415926; // define.h:56
+    for (int i = 0; i < 2 * len; i++) { // sample i/2: Real from draws 1-2, Image from draws 3-4 (LDPC_Encoder.cpp:53-67)
+        float u1 = random_module(seed), u2 = random_module(seed);
+        const float amp = std::sqrt(-2.0f * std::log(1.0f - u1));
+        rx[i] = (float)((double)sigma * std::cos(two_pi * (double)u2) * (double)amp + (double)tx[i]);
+    }
+    return NBLDPC_OK;
+}
+
+namespace {
+// One thread per (frame b, run of kNbRun consecutive samples): jump to draw 4*(b*len + i0), then step as RandomModule does.
+template <bool REAL_ONLY>
+__global__ __launch_bounds__(256) void k_nb_awgn_sym(unsigned s0, unsigned s1, unsigned s2, float sigma, const float *tx, int len, int B, float *rx)
+{
+    const int runs = (len + kNbRun - 1) / kNbRun;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)B * runs) return;
+    const int b = (int)(id / runs), i0 = (int)(id - (long long)b * runs) * kNbRun;
+    const unsigned long long k = 4ull * ((unsigned long long)b * len + i0);
+    unsigned s[3] = {s0, s1, s2};
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i] = (unsigned)(((unsigned long long)s[i] * nb_powmod(kNbA[i], k, kNbM[i])) % kNbM[i]);
+    const double two_pi = 2 * 3.1415926; // define.h:56
+    for (int i = i0; i < min(len, i0 + kNbRun); i++) {
+        float u[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) s[j] = (s[j] * kNbA[j]) % kNbM[j];
+            // correctly rounded x / m as a double product (see k_nb_awgn)
+            float t = (float)((double)(int)s[0] * (1.0 / 61967.0)) + (float)((double)(int)s[1] * (1.0 / 63443.0)) + (float)((double)(int)s[2] * (1.0 / 63599.0));
+            t -= (int)t;
+            u[d] = t;
+        }
+        const float a0 = sqrtf(-2.0f * logf(1.0f - u[0]));
+        const float re = (float)((double)sigma * cos(two_pi * (double)u[1]) * (double)a0 + (double)tx[2 * i]);
+        if (REAL_ONLY) {
+            rx[(size_t)b * len + i] = re;
+        } else {
+            const float a1 = sqrtf(-2.0f * logf(1.0f - u[2]));
+            const float im = (float)((double)sigma * cos(two_pi * (double)u[3]) * (double)a1 + (double)tx[2 * i + 1]);
+            *reinterpret_cast<float2 *>(rx + ((size_t)b * len + i) * 2) = make_float2(re, im);
+        }
+    }
+}
+} // namespace
+
+extern "C" int nbldpc_awgn_channel_device_sym(int seed[3], float sigma, const float *tx, int len, int B, int real_only, float *rx, void *stream)
+{
+    if (!seed || !tx || !rx || len <= 0 || B <= 0) return fail(NBLDPC_EINVAL, "nbldpc_awgn_channel_device_sym: bad argument");
+    for (int i = 0; i < 3; i++)
+        if (seed[i] < 0 || (unsigned)seed[i] >= kNbM[i]) return fail(NBLDPC_EINVAL, "seed[%d]=%d outside [0,%u)", i, seed[i], kNbM[i]);
+    const long long threads = (long long)B * ((len + kNbRun - 1) / kNbRun);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (real_only) hipLaunchKernelGGL(k_nb_awgn_sym<true>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned)seed[0], (unsigned)seed[1], (unsigned)seed[2], sigma, tx, len, B, rx);
+    else hipLaunchKernelGGL(k_nb_awgn_sym<false>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned)seed[0], (unsigned)seed[1], (unsigned)seed[2], sigma, tx, len, B, rx);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
+    return nbldpc_seed_jump(seed, 4ull * (unsigned long long)len * B);
+}
+
+extern "C" int nbldpc_seed_jump(int seed[3], unsigned long long draws)
+{
+    if (!seed) return fail(NBLDPC_EINVAL, "nbldpc_seed_jump: null seed");
+    for (int i = 0; i < 3; i++)
+        if (seed[i] < 0 || (unsigned)seed[i] >= kNbM[i]) return fail(NBLDPC_EINVAL, "seed[%d]=%d outside [0,%u)", i, seed[i], kNbM[i]);
+    for (int i = 0; i < 3; i++) seed[i] = (int)(((unsigned long long)seed[i] * nb_powmod(kNbA[i], draws, kNbM[i])) % kNbM[i]);
+    return NBLDPC_OK;
+}
+
+namespace {
+// errs[b] = number of symbols of frame b that differ from the transmitted word (Statistic, Simulation.cpp:264-267): one wave per frame
+__global__ __launch_bounds__(256) void k_nb_frame_errors(const int *out, const int *cw, int B, int N, int *errs)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    int e = 0;
+    for (int i = lane; i < N; i += 64) e += out[(size_t)b * N + i] != cw[i];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) e += __shfl_xor(e, o);
+    if (lane == 0) errs[b] = e;
+}
+} // namespace
+
+extern "C" int nbldpc_frame_errors(const nbldpc_code *c, const int *out, const int *cw, int B, int *errs, void *stream)
+{
+    if (!c || !out || !cw || !errs || B <= 0) return fail(NBLDPC_EINVAL, "nbldpc_frame_errors: bad argument");
+    hipLaunchKernelGGL(k_nb_frame_errors, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, cw, B, c->N, errs);
+    CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
 }
 

@@ -169,6 +169,9 @@ float bldpc_sigma(float SNR, int snrtype, float rate);
  * elapsed milliseconds in *ms.  Used by bench.py for the roofline line; off by default. */
 int bldpc_set_profiling(bldpc_code *code, int enable);
 int bldpc_last_kernel_ms(bldpc_code *code, float *ms);
+/* Mean over the decode calls made since the previous bldpc_kernel_ms_mean / bldpc_set_profiling (at most the last 64): every
+ * profiled call records its own event pair, nothing synchronises until this function is called.  *launches = calls averaged. */
+int bldpc_kernel_ms_mean(bldpc_code *code, float *mean_ms, int *launches);
 
 /* Name of the kernel variant the last bldpc_decode on this code used (static string). */
 const char *bldpc_last_kernel(const bldpc_code *code);

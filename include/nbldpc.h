@@ -88,6 +88,10 @@ int nbldpc_tmm_decode_batch(nbldpc_code *code, const float *L_ch, int B, int lay
  * rx float [B][N*m] (m = log2 q, bit b of symbol s at s*m+b) -> L_ch float [B][N][q-1]. */
 int nbldpc_demodulate_bpsk(const nbldpc_code *code, const float *rx, float sigma, int B, float *L_ch, void *stream);
 
+/* The same two without a code object (Demodulate needs the dimensions only): N symbols of GF(q). */
+int nbldpc_demodulate_bpsk_nq(int N, int q, const float *rx, float sigma, int B, float *L_ch, void *stream);
+int nbldpc_demodulate_qam_nq(int N, int q, const float *rx, const float *constellation, float sigma, int B, float *L_ch, void *stream);
+
 /* Device-side Statistic (src/Simulation.cpp:256-279) over a decoded batch: counters device int64[4],
  * ACCUMULATED: [0] num_Error_Frames [1] num_Error_Bits (symbol errors, sic) [2] Total_Iteration [3] frames ok.
  * CodeWord_sym: device int32 [N]. */
@@ -131,6 +135,28 @@ int nbldpc_awgn_channel_device_qam(int seed[3], float sigma, const int *CodeWord
  * rx float [B][N][2], constellation DEVICE float [q][2] -> L_ch float [B][N][q-1]. */
 int nbldpc_demodulate_qam(const nbldpc_code *code, const float *rx, const float *constellation, float sigma, int B, float *L_ch,
                           void *stream);
+
+/* ---- AWGNChannel_CPU exactly as the reference declares it (src/LDPC_Encoder.cpp:41-68): noise added to a MODULATED frame,
+ * whatever produced it -- len samples (bit_length for BPSK, Variablenode_num for n_QAM != 2), each a (Real, Image) pair with
+ * two RandomModule draws per part.  tx / rx: HOST float [len][2], i.e. the memory of a CComplex array (include/struct.h:9-14).
+ * nbldpc_awgn_channel_host / _host_qam above are this function composed with Modulate. */
+int nbldpc_awgn_channel_host_sym(int seed[3], float sigma, const float *tx, int len, float *rx);
+
+/* The same for B consecutive frames on the device (LCG jump-ahead per run of samples, device libm).  tx: DEVICE float [len][2];
+ * rx: DEVICE float [B][len] holding the Real parts only when real_only != 0 (what nbldpc_demodulate_bpsk takes), else
+ * DEVICE float [B][len][2] (nbldpc_demodulate_qam).  seed[3] (host) is advanced by B whole frames. */
+int nbldpc_awgn_channel_device_sym(int seed[3], float sigma, const float *tx, int len, int B, int real_only, float *rx, void *stream);
+
+/* RandomModule (src/LDPC_Encoder.cpp:70-79): one uniform draw, seed[3] advanced in place. */
+float nbldpc_random_module(int seed[3]);
+
+/* Advance the three LCGs of RandomModule (src/LDPC_Encoder.cpp:70-79) by `draws` calls: seed_i * a_i^draws mod m_i.  One frame
+ * of AWGNChannel_CPU is 4 * len draws. */
+int nbldpc_seed_jump(int seed[3], unsigned long long draws);
+
+/* Per-frame symbol errors against the transmitted word (the count Statistic makes, src/Simulation.cpp:264-267):
+ * DecodeOutput DEVICE int32 [B][N], CodeWord_sym DEVICE int32 [N] -> errs DEVICE int32 [B]. */
+int nbldpc_frame_errors(const nbldpc_code *code, const int *DecodeOutput, const int *CodeWord_sym, int B, int *errs, void *stream);
 
 /* sigma of a sweep point (src/main.cu:221-228). */
 float nbldpc_sigma(float SNR, int snrtype, int n_QAM, float rate);

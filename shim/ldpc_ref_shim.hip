@@ -18,6 +18,8 @@ struct Cfg {
     std::string path = "PON_LDPC.txt"; // Simulation.cu:296
     int as_written = 1;
     long leastErrorFrames = 50, leastTestFrames = 10000, displayStep = 40960; // define.cuh:52-54
+    int device_channel = 0, device_statistics = 0, exit_mode = BLDPC_EXIT_BATCH_GLOBAL; // bldpc_shim_configure_fast
+    long max_batches = 0;
 } g_cfg;
 bldpc_code *g_code = nullptr;
 int *g_D_dev = nullptr;
@@ -78,6 +80,16 @@ extern "C" int bldpc_shim_configure_sim(const char *path, int as_written, long l
     return BLDPC_OK;
 }
 
+extern "C" int bldpc_shim_configure_fast(int device_channel, int device_statistics, int exit_mode, long max_batches)
+{
+    if (exit_mode != BLDPC_EXIT_FIXED && exit_mode != BLDPC_EXIT_BATCH_GLOBAL && exit_mode != BLDPC_EXIT_PER_FRAME) return BLDPC_EINVAL;
+    if (exit_mode == BLDPC_EXIT_PER_FRAME && !device_statistics) return BLDPC_EINVAL; // the host Statistic takes ONE iteraTime per batch
+    if (max_batches < 0) return BLDPC_EINVAL;
+    g_cfg.device_channel = device_channel ? 1 : 0; g_cfg.device_statistics = device_statistics ? 1 : 0;
+    g_cfg.exit_mode = exit_mode; g_cfg.max_batches = max_batches;
+    return BLDPC_OK;
+}
+
 extern "C" void bldpc_shim_reset(void)
 {
     if (g_code) bldpc_code_destroy(g_code);
@@ -100,6 +112,32 @@ void Transform_H(int *H, int *Weight_Checknode, int *Weight_Variablenode, int *A
     if (bldpc_transform_h(H, c.J, c.L, c.Z, Weight_Checknode, Weight_Variablenode, Address_Variablenode, c.as_written)) die("Transform_H");
 }
 
+static void ensure_code(int *Address_Variablenode, int *Weight_Checknode, int *Weight_Variablenode)
+{
+    const Cfg &c = g_cfg;
+    const int N = c.L * c.Z;
+    if (g_code) return;
+    // the reference keeps the table on the device (main.cu:73,98); the builder wants it on the host once
+    std::vector<int> addr((size_t)N * Weight_Variablenode[c.L]), H;
+    if (hipMemcpy(addr.data(), Address_Variablenode, addr.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+        printf("Cannot copy Address_Variablenode to the host in LDPC_Decoder_GPU, exit!\n");
+        exit(0);
+    }
+    if (table_is_qc(c, Weight_Checknode, Weight_Variablenode, addr, H)) {
+        if (bldpc_code_create_qc(c.J, c.L, c.Z, H.data(), &g_code)) die("bldpc_code_create_qc");
+    } else if (bldpc_code_create_table(c.J, c.L, c.Z, Weight_Checknode, Weight_Variablenode, addr.data(), &g_code)) {
+        die("bldpc_code_create_table");
+    }
+}
+
+static void ensure_D(size_t d_bytes)
+{
+    if (d_bytes <= g_D_cap) return;
+    if (g_D_dev) (void)hipFree(g_D_dev);
+    if (hipMalloc((void **)&g_D_dev, d_bytes) != hipSuccess) { printf("Cannot malloc D_GPU in LDPC_Decoder_GPU on device, exit!\n"); exit(0); }
+    g_D_cap = d_bytes;
+}
+
 void LDPC_Decoder_GPU(int *D, float *Channel_Out, cudaDeviceProp prop, int *Address_Variablenode, int *Weight_Checknode,
                       int *Weight_Variablenode, LDPCCode *LDPC)
 {
@@ -107,29 +145,34 @@ void LDPC_Decoder_GPU(int *D, float *Channel_Out, cudaDeviceProp prop, int *Addr
     const Cfg &c = g_cfg;
     if (!c.J) { printf("bldpc_shim_configure was not called, exit!\n"); exit(0); }
     const int N = c.L * c.Z;
-    if (!g_code) {
-        // the reference keeps the table on the device (main.cu:73,98); the builder wants it on the host once
-        std::vector<int> addr((size_t)N * Weight_Variablenode[c.L]), H;
-        if (hipMemcpy(addr.data(), Address_Variablenode, addr.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
-            printf("Cannot copy Address_Variablenode to the host in LDPC_Decoder_GPU, exit!\n");
-            exit(0);
-        }
-        if (table_is_qc(c, Weight_Checknode, Weight_Variablenode, addr, H)) {
-            if (bldpc_code_create_qc(c.J, c.L, c.Z, H.data(), &g_code)) die("bldpc_code_create_qc");
-        } else if (bldpc_code_create_table(c.J, c.L, c.Z, Weight_Checknode, Weight_Variablenode, addr.data(), &g_code)) {
-            die("bldpc_code_create_table");
-        }
-    }
+    ensure_code(Address_Variablenode, Weight_Checknode, Weight_Variablenode);
     const size_t d_bytes = (size_t)(N + 1) * c.F * sizeof(int);
-    if (d_bytes > g_D_cap) {
-        if (g_D_dev) (void)hipFree(g_D_dev);
-        if (hipMalloc((void **)&g_D_dev, d_bytes) != hipSuccess) { printf("Cannot malloc D_GPU in LDPC_Decoder_GPU on device, exit!\n"); exit(0); }
-        g_D_cap = d_bytes;
-    }
-    if (bldpc_decode(g_code, Channel_Out, c.F, c.maxIT, c.length, BLDPC_EXIT_BATCH_GLOBAL, BLDPC_KERNEL_AUTO, g_D_dev, nullptr, nullptr,
+    ensure_D(d_bytes);
+    if (bldpc_decode(g_code, Channel_Out, c.F, c.maxIT, c.length, c.exit_mode == BLDPC_EXIT_FIXED ? BLDPC_EXIT_FIXED : BLDPC_EXIT_BATCH_GLOBAL, BLDPC_KERNEL_AUTO, g_D_dev, nullptr, nullptr,
                      &LDPC->iteraTime, nullptr))
         die("bldpc_decode");
     if (hipMemcpy(D, g_D_dev, d_bytes, hipMemcpyDeviceToHost) != hipSuccess) { printf("Cannot copy D_GPU to D, exit!\n"); exit(0); }
+}
+
+// The tail of Statistic (Simulation.cu:264-284): the result row every displayStep frames, again when the stop rule is met (the
+// reference prints it twice when both fall on the same batch), 1 when the stop rule is met.  `last`: a max_batches stop.
+static bool g_last_batch = false; // Simulation_GPU -> Statistic: this batch ends the point by max_batches
+static int rows_and_stop(Simulation *SIM, bool last)
+{
+    const Cfg &c = g_cfg;
+    const bool stop = SIM->num_Error_Frames >= c.leastErrorFrames && SIM->num_Frames >= c.leastTestFrames;
+    auto row = [&]() {
+        SIM->BER = (float)(((double)SIM->num_Error_Bits / (double)SIM->num_Frames) / (double)c.length);
+        SIM->FER = (float)((double)SIM->num_Error_Frames / (double)SIM->num_Frames);
+        SIM->AverageIT = (float)((double)SIM->Total_Iteration / (double)SIM->num_Frames);
+        SIM->FER_Alarm = (float)((double)SIM->num_Alarm_Frames / (double)SIM->num_Frames);
+        SIM->FER_False = (float)((double)SIM->num_False_Frames / (double)SIM->num_Frames);
+        printf(" %.1f %8ld  %4ld  %6.4e  %6.4e  %.2f  %6.4e %6.4e\n", SIM->SNR, SIM->num_Frames, SIM->num_Error_Frames, SIM->FER, SIM->BER,
+               SIM->AverageIT, SIM->FER_False, SIM->FER_Alarm);
+    };
+    if (SIM->num_Frames % c.displayStep == 0) row();
+    if (stop || (last && SIM->num_Frames % c.displayStep != 0)) row();
+    return stop ? 1 : 0;
 }
 
 int Statistic(Simulation *SIM, int *CodeWord_Frames, int *D, LDPCCode *LDPC)
@@ -149,19 +192,7 @@ int Statistic(Simulation *SIM, int *CodeWord_Frames, int *D, LDPCCode *LDPC)
         SIM->num_False_Frames += (err[f] != 0 && flag[f] == 1);
         SIM->Total_Iteration += LDPC->iteraTime; // batch-global count, once per frame (Simulation.cu:262)
     }
-    const bool stop = SIM->num_Error_Frames >= c.leastErrorFrames && SIM->num_Frames >= c.leastTestFrames;
-    auto row = [&]() {
-        SIM->BER = (float)(((double)SIM->num_Error_Bits / (double)SIM->num_Frames) / (double)Length);
-        SIM->FER = (float)((double)SIM->num_Error_Frames / (double)SIM->num_Frames);
-        SIM->AverageIT = (float)((double)SIM->Total_Iteration / (double)SIM->num_Frames);
-        SIM->FER_Alarm = (float)((double)SIM->num_Alarm_Frames / (double)SIM->num_Frames);
-        SIM->FER_False = (float)((double)SIM->num_False_Frames / (double)SIM->num_Frames);
-        printf(" %.1f %8ld  %4ld  %6.4e  %6.4e  %.2f  %6.4e %6.4e\n", SIM->SNR, SIM->num_Frames, SIM->num_Error_Frames, SIM->FER, SIM->BER,
-               SIM->AverageIT, SIM->FER_False, SIM->FER_Alarm);
-    };
-    if (SIM->num_Frames % c.displayStep == 0) row();
-    if (stop) row(); // the reference prints the row again when both conditions fall on the same batch
-    return stop ? 1 : 0;
+    return rows_and_stop(SIM, g_last_batch);
 }
 
 void Simulation_GPU(AWGNChannel *AWGN, float *sigma_GPU, Simulation *SIM, int *Address_Variablenode, int *Weight_Checknode,
@@ -175,23 +206,60 @@ void Simulation_GPU(AWGNChannel *AWGN, float *sigma_GPU, Simulation *SIM, int *A
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { printf("There is no GPU beyond 1.0, exit!\n"); exit(0); }
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { printf("Cannot get device properties, exit!\n"); exit(0); }
-    std::vector<int> CodeWord(N * F, 0), D((N + 1) * F); // PN_Message 0: the all-zero codeword (Simulation.cu:96-106)
-    std::vector<float> Channel_Out(N * F);
+    // host copies only where the host needs them: PN_Message 0, the all-zero codeword (Simulation.cu:96-106)
+    std::vector<int> CodeWord(c.device_statistics ? 0 : N * F, 0), D(c.device_statistics ? 0 : (N + 1) * F);
+    std::vector<float> Channel_Out(c.device_channel ? 0 : N * F);
     float *Channel_Out_GPU = nullptr;
     if (hipMalloc((void **)&Channel_Out_GPU, N * F * sizeof(float)) != hipSuccess) {
         printf("Cannot malloc Channel_Out_GPU in SNR_Simulation_GPU on device, exit!\n");
         exit(0);
     }
     LDPCCode LDPC;
-    for (;;) {
-        SIM->num_Frames += c.F;
-        if (bldpc_awgn_channel_host(AWGN->seed, AWGN->sigma, Channel_Out.data(), CodeWord.data(), (int)N, c.F)) die("AWGNChannel_CPU");
-        if (hipMemcpy(Channel_Out_GPU, Channel_Out.data(), N * F * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-            printf("Cannot copy Channel_Out to the device, exit!\n");
-            exit(0);
-        }
-        LDPC_Decoder_GPU(D.data(), Channel_Out_GPU, prop, Address_Variablenode, Weight_Checknode, Weight_Variablenode, &LDPC);
-        if (Statistic(SIM, CodeWord.data(), D.data(), &LDPC) == 1) break;
+    const bool fast_stats = c.device_statistics != 0;
+    long long *cnt_dev = nullptr, *cnt_host = nullptr; // the five counters of one batch
+    int *iters_dev = nullptr;
+    if (fast_stats) {
+        ensure_code(Address_Variablenode, Weight_Checknode, Weight_Variablenode);
+        ensure_D((N + 1) * F * sizeof(int));
+        bool good = hipMalloc((void **)&cnt_dev, 5 * sizeof(long long)) == hipSuccess && hipHostMalloc((void **)&cnt_host, 5 * sizeof(long long), hipHostMallocDefault) == hipSuccess;
+        if (c.exit_mode == BLDPC_EXIT_PER_FRAME) good = good && hipMalloc((void **)&iters_dev, F * sizeof(int)) == hipSuccess;
+        if (!good) { printf("Cannot malloc the counters on device, exit!\n"); exit(0); }
     }
+    for (long batches = 1;; batches++) {
+        SIM->num_Frames += c.F; // Simulation.cu:113
+        if (c.device_channel) {
+            if (bldpc_awgn_channel_device(AWGN->seed, AWGN->sigma, Channel_Out_GPU, nullptr, (int)N, c.F, nullptr)) die("AWGNChannel (device)");
+        } else {
+            if (bldpc_awgn_channel_host(AWGN->seed, AWGN->sigma, Channel_Out.data(), nullptr, (int)N, c.F)) die("AWGNChannel_CPU"); // NULL: all-zero word
+            if (hipMemcpy(Channel_Out_GPU, Channel_Out.data(), N * F * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                printf("Cannot copy Channel_Out to the device, exit!\n");
+                exit(0);
+            }
+        }
+        const bool last = c.max_batches > 0 && batches >= c.max_batches;
+        int stop;
+        if (fast_stats) { // LDPC_Decoder_GPU + Statistic (Simulation.cu:143-145) as one device-side call; 40 bytes come back
+            (void)hipMemsetAsync(cnt_dev, 0, 5 * sizeof(long long), nullptr);
+            if (bldpc_decode_statistic(g_code, Channel_Out_GPU, c.F, c.maxIT, c.length, c.exit_mode, BLDPC_KERNEL_AUTO, g_D_dev, iters_dev, cnt_dev,
+                                       &LDPC.iteraTime, nullptr))
+                die("bldpc_decode_statistic");
+            if (hipMemcpyAsync(cnt_host, cnt_dev, 5 * sizeof(long long), hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+                printf("Cannot copy the counters to the host, exit!\n");
+                exit(0);
+            }
+            SIM->num_Error_Frames += cnt_host[0]; SIM->num_Error_Bits += cnt_host[1]; SIM->Total_Iteration += cnt_host[2];
+            SIM->num_False_Frames += cnt_host[3]; SIM->num_Alarm_Frames += cnt_host[4];
+            stop = rows_and_stop(SIM, last);
+        } else {
+            LDPC_Decoder_GPU(D.data(), Channel_Out_GPU, prop, Address_Variablenode, Weight_Checknode, Weight_Variablenode, &LDPC);
+            g_last_batch = last;
+            stop = Statistic(SIM, CodeWord.data(), D.data(), &LDPC);
+            g_last_batch = false;
+        }
+        if (stop == 1 || last) break;
+    }
+    if (cnt_dev) (void)hipFree(cnt_dev);
+    if (cnt_host) (void)hipHostFree(cnt_host);
+    if (iters_dev) (void)hipFree(iters_dev);
     (void)hipFree(Channel_Out_GPU);
 }

@@ -43,6 +43,16 @@ extern "C" int bldpc_shim_configure(int J, int L, int Z, int frames, int length,
 // as_written: 1 = Transform_H reproduces Simulation.cu:380 literally (the reference's table, default), 0 = the intended
 // circulant; leastErrorFrames / leastTestFrames / displayStep: define.cuh:52-54 (defaults 50 / 10000 / 40960).
 extern "C" int bldpc_shim_configure_sim(const char *path, int as_written, long leastErrorFrames, long leastTestFrames, long displayStep);
+// The fast path through the same Simulation_GPU (default: all zero = the reference's data flow, bit-exact host noise stream):
+//   device_channel     1: bldpc_awgn_channel_device instead of the host AWGNChannel_CPU + upload (same RandomModule draws by LCG
+//                         jump-ahead, device libm in the Box-Muller transform: a sample may differ by an ulp)
+//   device_statistics  1: bldpc_decode_statistic -- decode and Statistic in one call on the device, only the five counters come
+//                         back per batch (no 4 N F-byte copy of D, no host loop over it)
+//   exit_mode          BLDPC_EXIT_BATCH_GLOBAL (the reference's rule, default), BLDPC_EXIT_FIXED, or BLDPC_EXIT_PER_FRAME (every
+//                         frame stops on its own flag = the reference with Num_Frames_OneTime 1; needs device_statistics)
+//   max_batches        stop a point after this many batches even if the stop rule is not met (0 = never; deep sweeps)
+// Counters, rows and seeds are those of the Python mirror cuda_ldpc_amd.simulation.Simulation_GPU with the same switches.
+extern "C" int bldpc_shim_configure_fast(int device_channel, int device_statistics, int exit_mode, long max_batches);
 extern "C" void bldpc_shim_reset(void); // drop the cached code object (e.g. before switching matrices)
 extern "C" const char *bldpc_shim_last_kernel(void); // which kernel tier the last LDPC_Decoder_GPU call ran on
 

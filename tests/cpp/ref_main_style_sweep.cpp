@@ -4,6 +4,7 @@
 // come from the command line.  Prints the reference's result rows and, per point, a line "POINT snr frames error_frames
 // error_bits total_iteration false alarm" for the test that compares it with cuda_ldpc_amd.simulation.
 // usage: ref_main_style_sweep <BlockH.txt> J L Z F maxIT as_written startSNR stopSNR stepSNR leastErrorFrames leastTestFrames
+//                             [device_channel device_statistics exit_mode max_batches]     (bldpc_shim_configure_fast; default 0 0 1 0)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +19,8 @@ int main(int argc, char **argv)
     const double startSNR = atof(argv[8]), stopSNR = atof(argv[9]), stepSNR = atof(argv[10]);
     const int CW_Len = L * Z, msgLen = CW_Len - J * Z;
     if (bldpc_shim_configure(J, L, Z, F, msgLen, maxIT)) return 1;
-    if (bldpc_shim_configure_sim(argv[1], as_written, atol(argv[11]), atol(argv[12]), 40960)) return 1;
+    if (bldpc_shim_configure_sim(argv[1], as_written, atol(argv[11]), atol(argv[12]), argc >= 17 ? (1L << 62) : 40960)) return 1;
+    if (argc >= 17 && bldpc_shim_configure_fast(atoi(argv[13]), atoi(argv[14]), atoi(argv[15]), atol(argv[16]))) return 1;
 
     AWGNChannel *AWGN = (AWGNChannel *)malloc(sizeof(AWGNChannel));
     Simulation *SIM = (Simulation *)malloc(sizeof(Simulation));

@@ -426,6 +426,50 @@ def test_reference_main_style_sweep_cpp_harness(C, orc, tmp_path, as_written):
     assert len(rows) >= 3  # the reference's result rows (Simulation.cu:272)
 
 
+@pytest.mark.parametrize("exit_mode", [2, 1, 0])
+def test_reference_main_style_sweep_fast_path(C, tmp_path, exit_mode):
+    """The fast path through the binary drop-in boundary (bldpc_shim_configure_fast): the same main.cu-style C++ sweep with the
+    device-side channel and bldpc_decode_statistic behind the reference-signature Simulation_GPU -- no host channel, no copy of D,
+    no host loop.  Counters per point equal the Python mirror (cuda_ldpc_amd.simulation.Simulation_GPU) with the same switches:
+    same draws, same device libm, same kernels."""
+    import subprocess
+    from cuda_ldpc_amd._lib import SO_PATH
+    from cuda_ldpc_amd.simulation import Simulation_GPU
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    exe = _build_cpp(root, SO_PATH, tmp_path, "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+    J, L, Z, F, maxIT = 4, 24, 96, 4096, 50
+    out = subprocess.check_output([exe, _path(J, L, Z), str(J), str(L), str(Z), str(F), str(maxIT), "0", "3.0", "3.3", "0.2", "20", "8192",
+                                   "1", "1", str(exit_mode), "0"]).decode()
+    pts = [ln.split() for ln in out.splitlines() if ln.startswith("POINT")]
+    assert len(pts) == 2 and "task finish" in out
+    code = C.BinaryCode.from_blockh(_path(J, L, Z), J, L, Z)
+    snr = np.float32(3.0)
+    for p in pts:
+        seed = np.array([173, 173, 173], np.int32)
+        SIM = C.SimCounters()
+        SIM.SNR = float(snr)
+        Simulation_GPU(code, seed, C.sigma_of(float(snr)), SIM, Num_Frames_OneTime=F, maxIT=maxIT, exit_mode=exit_mode, leastErrorFrames=20,
+                       leastTestFrames=8192, device_channel=True, log=None)
+        assert [int(x) for x in p[2:8]] == [SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, SIM.num_False_Frames,
+                                            SIM.num_Alarm_Frames], (p, SIM)
+        assert p[8].startswith("kernel=qc_lds"), p[8]
+        snr = np.float32(np.float64(snr) + 0.2)
+
+
+def test_reference_main_style_sweep_fast_path_reproduces_the_committed_sweep(C, tmp_path):
+    """Two Es/N0 points of profiles/r02c_sweep_binary_J4_L24_Z96_per_frame_exit.txt (sweep.py binary --device-channel --per-frame
+    --batch 262144), count for count, from the C++ harness: 3.0 dB 262144 frames / 575 error frames, 3.2 dB 262144 / 56."""
+    import subprocess
+    from cuda_ldpc_amd._lib import SO_PATH
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    exe = _build_cpp(root, SO_PATH, tmp_path, "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+    out = subprocess.check_output([exe, _path(4, 24, 96), "4", "24", "96", "262144", "50", "0", "3.0", "3.3", "0.2", "50", "10000",
+                                   "1", "1", "2", "1200"]).decode()
+    rows = [ln.split() for ln in out.splitlines() if ln.startswith(" 3.")]
+    assert [r[:3] for r in rows] == [["3.0", "262144", "575"], ["3.2", "262144", "56"]], out
+    assert rows[0][3:6] == ["2.1935e-03", "3.5749e-05", "6.65"] and rows[1][3:6] == ["2.1362e-04", "3.0259e-06", "5.36"], rows
+
+
 def test_max_iter_above_64_falls_back_to_the_table_kernels(C, orc):
     """The reference takes any maxIT (define.cuh:35).  The fused kernels keep 64 iterations of flag history, so
     KERNEL_AUTO sends a batch-global decode with max_iter > 64 to the table kernels instead of refusing it; an explicit
@@ -473,6 +517,37 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(C):
     for k in ("frames", "error_frames", "error_bits"):
         assert j2["stats"][k] == 2 * j1["stats"][k], (k, j1["stats"], j2["stats"])
     assert j1["stats"]["error_frames"] > 0
+
+
+def test_rccl_world_size_one_smoke(C):
+    """RCCL on the one GPU there is: ONE fresh child process (python -m torch.distributed.run --nproc-per-node 1) initialises
+    init_process_group("nccl", device_id=cuda:0) before it touches the GPU, runs Simulation_GPU(..., dist=dist) for two batches and
+    the counter all-reduce of sharding.allreduce_counters; its counters equal the un-distributed run made here.  Proves that
+    librccl loads and the collective of the multi-GPU path executes on MI355X (not a scaling measurement)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from cuda_ldpc_amd.simulation import Simulation_GPU
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "rccl_world1_child.py")], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["backend"] == "nccl" and j["world"] == 1 and j["rccl_loaded"] and j["probe"] == [0, 1, 2, 3, 4]
+    code = C.BinaryCode.from_blockh(_path(4, 24, 96), 4, 24, 96)
+    seed = np.array([173, 173, 173], np.int32)
+    SIM = C.SimCounters()
+    Simulation_GPU(code, seed, C.sigma_of(3.0), SIM, Num_Frames_OneTime=2048, maxIT=50, exit_mode=C.EXIT_PER_FRAME, max_batches=2, log=None,
+                   device_channel=True)
+    assert [j["frames"], j["error_frames"], j["error_bits"], j["total_iteration"], j["seed"]] == \
+        [SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration, seed.tolist()]
+    assert j["frames"] == 4096 and j["error_frames"] > 0
 
 
 def test_bench_contract_line(C):
@@ -739,3 +814,49 @@ def test_batch_global_when_a_frame_loses_its_flag_again(C, orc, snr, length, s0,
         _assert_same(got, want, code.N, F)
         mask = np.uint64((1 << want["it"]) - 1)
         assert np.array_equal(got["flag_hist"] & mask, want["flag_hist"] & mask)
+
+
+# ---- the persistent-workgroup instantiations (frames from per-XCD counters) are only reached by LARGE batches ------------------------
+PERSIST_CODES = [("J4_L24_Z96_BlockH.txt", 4, 24, 96, 3.0, 8192, "halfrow"),     # k_qc2p: grid 4096 pairs > 512 resident workgroups
+                 ("J32_L64_Z64_BlockH.txt", 32, 64, 64, -0.6, 4096, "row"),      # k_qcp
+                 ("PON_LDPC.txt", 12, 69, 256, 2.5, 2048, "regs"),               # k_qcr<PERSIST>
+                 ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, -0.8, 1024, "regs")] # k_qcr2<PERSIST>
+
+
+@pytest.mark.parametrize("fn,J,L,Z,snr,F,tag", PERSIST_CODES)
+def test_persistent_kernels_equal_one_workgroup_per_frame_group(C, orc, monkeypatch, fn, J, L, Z, snr, F, tag):
+    """Batches large enough for the persistent form of every fused tier (grid > resident workgroups): per-frame exit and the
+    batch-global rule (whose pre-pass is a per-frame pass) give the same D, iteration counts and a-posteriori sums, bit for bit, as
+    a code object created under BLDPC_NO_PERSIST=1 (one workgroup per frame group; the switch is read when the code is created),
+    and a sample of frames equals the oracle's decode of that frame alone."""
+    p = os.path.join(BL, fn)
+    code = C.BinaryCode.from_blockh(p, J, L, Z)
+    monkeypatch.setenv("BLDPC_NO_PERSIST", "1")
+    plain = C.BinaryCode.from_blockh(p, J, L, Z)
+    monkeypatch.delenv("BLDPC_NO_PERSIST")
+    seed = np.array([173, 173, 173], np.int32)
+    yt = C.AWGNChannel_GPU(seed, C.sigma_of(snr), code.N, F)
+    a = C.LDPC_Decoder_GPU(code, yt, max_iter=50, exit_mode=C.EXIT_PER_FRAME, want_app=True)
+    b = C.LDPC_Decoder_GPU(plain, yt, max_iter=50, exit_mode=C.EXIT_PER_FRAME, want_app=True)
+    torch.cuda.synchronize()
+    it = a["iters"].cpu().numpy()
+    assert len(set(it.tolist())) > 3, "pick an SNR at which frames stop at different iterations"
+    assert torch.equal(a["iters"], b["iters"]) and torch.equal(a["D"], b["D"])
+    assert torch.equal(a["app"].view(torch.int32), b["app"].view(torch.int32))
+    ocode = orc.BinaryCode(p, J, L, Z)
+    pick = [0, 1, F // 2 + 1, F - 1]
+    y = yt[:, pick].cpu().numpy()
+    Dw, appw, itw = _oracle_per_frame(orc, ocode, np.ascontiguousarray(y), len(pick), 50)
+    D, app = a["D"][:, pick].cpu().numpy(), a["app"][:, pick].cpu().numpy()
+    assert np.array_equal(it[pick], itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
+    # the reference's batch-global rule on the same batch: its pre-pass runs the persistent kernel too
+    ga = C.LDPC_Decoder_GPU(code, yt, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
+    gb = C.LDPC_Decoder_GPU(plain, yt, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True)
+    torch.cuda.synchronize()
+    assert ga["iteraTime"] == gb["iteraTime"] and ga["iteraTime"] >= int(it.max())  # no earlier than the latest first flag
+    assert torch.equal(ga["D"], gb["D"]) and torch.equal(ga["app"].view(torch.int32), gb["app"].view(torch.int32))
+    w = orc.bldpc_decode(ocode, np.ascontiguousarray(y), len(pick), ga["iteraTime"], early_exit=0, want_app=True)  # the same iterations, fixed
+    assert np.array_equal(ga["D"][:code.N, pick].cpu().numpy().reshape(-1), w["D"][:code.N * len(pick)])
+    assert np.array_equal(ga["app"][:, pick].cpu().numpy().reshape(-1).view(np.uint32), w["app"].view(np.uint32))
+    assert tag in code.last_kernel or "qc_lds" in code.last_kernel
+

@@ -591,6 +591,94 @@ def test_reference_signature_shim_cpp_harness(nb, code, orc, tmp_path, method, t
         assert line == want, (line, want)
 
 
+def _build_nb_main(tmp_path):
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from cuda_ldpc_amd._lib import SO_PATH
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    exe = str(tmp_path / "nb_ref_main_style_sweep")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "shim"),
+                           os.path.join(root, "tests", "cpp", "nb_ref_main_style_sweep.cpp"), os.path.join(root, "shim", "nbldpc_ref_shim.hip"),
+                           "-o", exe, "-L", os.path.dirname(SO_PATH), "-lcuda_ldpc_amd", "-Wl,-rpath," + os.path.dirname(SO_PATH), "-pthread"])
+    return exe
+
+
+def _run_nb_main(exe, *args):
+    import subprocess
+    out = subprocess.check_output([exe] + [str(a) for a in args], cwd=NB).decode()  # cwd: the reference's relative paths (define.h:23-24, GF.cpp:81)
+    assert "task finish" in out, out
+    pts = [ln.split() for ln in out.splitlines() if ln.startswith("POINT")]
+    frames = [ln.split() for ln in out.splitlines() if ln.startswith("FRAME")]
+    rows = [ln for ln in out.splitlines() if ln.startswith(" ") and ln.rstrip().endswith("sec")]
+    return pts, frames, rows
+
+
+@pytest.mark.parametrize("cpu_gpu", [1, 0])
+def test_reference_main_style_nb_sweep_cpp_harness(nb, code, ocode, orc, tmp_path, cpu_gpu):
+    """The NB half of the drop-in boundary: a main() written like myNBLDPC/src/main.cu:14-268 -- Get_H, GFInitial,
+    Get_CONSTELLATION, Modulate, the Eb/N0 loop with Simulation_GPU (CPU_GPU 1, the reference's default) or Simulation_CPU, all
+    with the reference's signatures -- linked against shim/nbldpc_ref_shim.hip and the library only.  The shim decodes 64 frames
+    per launch; per point, frames / error frames / symbol errors / Total_Iteration and the AWGN seeds equal a frame-by-frame
+    replay of decode_once_* (Simulation.cpp:115-158) through the oracle, and the first 16 frames at 3 dB equal the
+    reference's own dump (tests/golden/nb_ref_3dB.npz)."""
+    exe = _build_nb_main(tmp_path)
+    cwf = os.path.join(NB, "codeword_bds_gf64.txt")
+    pts, frames, rows = _run_nb_main(exe, "BDS.576.288.GF.64.txt", cwf, 64, 4, 2, 0, cpu_gpu, 2.0, 3.01, 1.0, 6, 20, 64, 0, 0)
+    assert len(pts) == 2 and len(rows) == 2  # 2.0 and 3.0 dB; one result row per finished point (Simulation.cpp:198,241)
+    cw = np.loadtxt(cwf, dtype=np.int32)
+    for p, snr in zip(pts, (2.0, 3.0)):
+        assert abs(float(p[1]) - snr) < 1e-6
+        sigma = orc.nb_sigma(snr, ocode.rate)
+        oseed = np.array([173, 173, 173], np.int32)
+        nfr = errf = errb = its = 0
+        while errf < 6 or nfr < 20:  # Simulation.cpp:115
+            rx, Lch = orc.nb_channel(ocode, cw, oseed, sigma)
+            r = orc.nb_ems_decode(ocode, Lch, 2, 2, 20)
+            nfr += 1
+            its += r["it"]
+            e = int((r["out"] != cw).sum())
+            errb += e
+            errf += 1 if e else 0
+        assert [int(x) for x in p[2:9]] == [nfr, errf, errb, its] + oseed.tolist(), (p, nfr, errf, errb, its, oseed)
+    # the first 16 frames of the 3 dB point against the reference's own outputs
+    g = np.load(os.path.join(GOLDEN, "nb_ref_3dB.npz"))
+    pts, frames, _ = _run_nb_main(exe, "BDS.576.288.GF.64.txt", cwf, 64, 4, 2, 0, cpu_gpu, 3.0, 3.01, 1.0, 50, 1000, 512, 0, 16)
+    assert len(frames) == 16
+    for fr, ln in enumerate(frames):
+        assert [int(ln[1]), int(ln[2]), int(ln[3])] == [fr, int(g["ok"][fr]), int(g["it"][fr])], ln
+        assert int(ln[4], 16) == orc.fold_hash(g["out"][fr]), ln
+    assert int(pts[0][2]) >= 1000 and int(pts[0][3]) >= 50  # the reference's stop rule (define.h:52-53)
+
+
+@pytest.mark.parametrize("method,cpu_gpu", [(1, 1), (3, 0), (2, 1)])
+def test_nb_sweep_cpp_harness_fast_mode_equals_python_loop(nb, code, tmp_path, method, cpu_gpu):
+    """The same harness with the device-side channel (cfg.device_channel = 1: no host loop, no upload) and the other
+    decoder_method values: counters and seeds equal cuda_ldpc_amd.nb_simulation.Simulation_GPU on the same device channel
+    (same draws, same device libm), whatever the two batch sizes are."""
+    from cuda_ldpc_amd.nb_simulation import NBSim, Simulation_GPU
+    exe = _build_nb_main(tmp_path)
+    cwf = os.path.join(NB, "codeword_bds_gf64.txt")
+    cw = np.loadtxt(cwf, dtype=np.int32)
+    pts, _, _ = _run_nb_main(exe, "BDS.576.288.GF.64.txt", cwf, 64, 4, 2, method, cpu_gpu, 2.5, 2.51, 1.0, 30, 1500, 1000, 1, 0)
+    sigma = nb.sigma_of(2.5, code.rate)
+    seed = np.array([173, 173, 173], np.int32)
+    SIM = NBSim(2.5)
+    assert Simulation_GPU(code, seed, sigma, SIM, cw, batch=384, leastErrorFrames=30, leastTestFrames=1500, device_channel=True, decoder_method=method) == 1
+    assert [int(x) for x in pts[0][2:9]] == [SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration] + seed.tolist()
+
+
+def test_nb_simulation_gpu_refuses_layered_tmm_like_the_reference(nb, tmp_path):
+    """decode_once_gpu prints "unfinished" and exits for decoder_method 3 (Simulation.cpp:140-144); so does the shim's Simulation_GPU."""
+    import subprocess
+    exe = _build_nb_main(tmp_path)
+    r = subprocess.run([exe, "BDS.576.288.GF.64.txt", os.path.join(NB, "codeword_bds_gf64.txt"), "64", "4", "2", "3", "1", "3.0", "3.01", "1.0", "5", "10",
+                        "64", "0", "0"], cwd=NB, capture_output=True, text=True)
+    assert r.returncode == 0 and "unfinished" in r.stdout and "POINT" not in r.stdout
+
+
 # ---- QAM constellations (n_QAM = q).  PARITY UNPINNED against the reference (define.h fixes n_QAM = 2; nothing in its tree
 # records an output of these branches): the checker is the oracle's restatement of the source text. -----------------------------
 @pytest.fixture(scope="module")
@@ -676,3 +764,46 @@ def test_qam_device_channel_and_simulation_loop(nb, code, ocode, orc, qam64):
         errf += 1 if e else 0
     assert (SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration) == (frames, errf, errb, its)
     assert np.array_equal(seed, oseed)
+
+
+@pytest.mark.parametrize("which", ["tmm", "ltmm", "ems64", "gf256"])
+def test_persistent_nb_kernels_equal_one_workgroup_per_frame(nb, orc, monkeypatch, which):
+    """Batches larger than the resident grid take the persistent form of the GF(q) kernels (frames from an atomic counter): same
+    symbols, iteration counts, flags and final LLR / L_c2v bits as a code object created under NBLDPC_NO_PERSIST=1 (one workgroup
+    per frame; the switch is read when the code is created), plus a sample of frames against the oracle."""
+    q = 256 if which == "gf256" else 64
+    mfile = "LDPC_N96_K48_GF256_d1_exp.txt" if q == 256 else "BDS.576.288.GF.64.txt"
+    gff = os.path.join(NB, "GF", "Arith.Table.GF.%d.txt" % q)
+    mul, _, _ = nb.GFInitial(q, gff)
+    code = nb.NBCode(os.path.join(NB, mfile), mul)
+    monkeypatch.setenv("NBLDPC_NO_PERSIST", "1")
+    plain = nb.NBCode(os.path.join(NB, mfile), mul)
+    monkeypatch.delenv("NBLDPC_NO_PERSIST")
+    ocode = orc.NBCode(os.path.join(NB, mfile), gff)
+    B = 1536
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32) if q == 64 else np.zeros(code.N, np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(4.0 if q == 256 else 2.8, code.rate)
+    rx = nb.AWGNChannel_GPU(seed, sigma, code, torch.from_numpy(cw).cuda(), B)
+    Lch = nb.Demodulate(code, rx, sigma)
+
+    def run(c):
+        if which in ("tmm", "ltmm"):
+            return nb.Decoding_TMM(c, Lch, 20, layered=(which == "ltmm"), want_state=True)
+        return nb.Decoding_EMS(c, Lch, 2, 2, 20, want_state=True)
+    a, b = run(code), run(plain)
+    torch.cuda.synchronize()
+    for k in ("DecodeOutput", "iter_number", "ok"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("LLR", "L_c2v"):
+        assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+    assert len(set(a["iter_number"].cpu().tolist())) > 3
+    Lh = Lch.cpu().numpy()
+    for f in (0, 1, B // 2 + 3, B - 1):
+        if which in ("tmm", "ltmm"):
+            w = orc.nb_tmm_decode(ocode, Lh[f], 20, layered=(which == "ltmm"), want_state=True)
+        else:
+            w = orc.nb_ems_decode(ocode, Lh[f], 2, 2, 20, want_state=True)
+        assert int(a["iter_number"][f]) == w["it"] and int(a["ok"][f]) == w["ok"] and np.array_equal(a["DecodeOutput"][f].cpu().numpy(), w["out"])
+        assert np.array_equal(a["LLR"][f].cpu().numpy().view(np.uint32), w["LLR"].view(np.uint32))
+
