@@ -4,7 +4,10 @@
 // of main.cu:120-127 so that a sweep driven through this library sees bit-identical channel
 // samples.  The reference is C++: log/sqrt on float arguments are the float overloads, the
 // sin argument is double (PI is the double literal 3.1415926, define.cuh:58).
+#include <algorithm>
 #include <cmath>
+#include <thread>
+#include <vector>
 
 #include "../../include/bldpc.h"
 #include "common.hpp"
@@ -20,21 +23,6 @@ inline float random_module(int *seed) // LDPC_Encoder.cu:45-56
     return t;
 }
 } // namespace
-
-extern "C" int bldpc_awgn_channel_host(int seed[3], float sigma, float *out, const int *cw, int N, int F)
-{
-    if (!seed || !out || N <= 0 || F <= 0) return cldpc::fail(BLDPC_EINVAL, "bldpc_awgn_channel_host: bad argument");
-    const double two_pi = 2 * 3.1415926;
-    for (int f = 0; f < F; f++)
-        for (int n = 0; n < N; n++) {
-            const float u1 = random_module(seed);
-            const float u2 = random_module(seed);
-            const float amp = std::sqrt(-2.0f * std::log(1.0f - u1));
-            const int c = cw ? cw[(size_t)n * F + f] : 0;
-            out[(size_t)n * F + f] = (float)((double)sigma * std::sin(two_pi * (double)u2) * (double)amp + 1.0 - (double)(2 * c));
-        }
-    return BLDPC_OK;
-}
 
 namespace {
 constexpr unsigned kA[3] = {249u, 251u, 252u}, kM[3] = {61967u, 63443u, 63599u}; // LDPC_Encoder.cu:48-50
@@ -54,6 +42,56 @@ __host__ __device__ inline unsigned powmod(unsigned a, unsigned long long k, uns
     return r;
 }
 
+// frames [f0, f1) of the serial loop (LDPC_Encoder.cu:30-38: frame outer, bit inner), seed = the stream state before frame f0
+void awgn_frames(int *seed, float sigma, float *out, const int *cw, int N, int F, int f0, int f1)
+{
+    const double two_pi = 2 * 3.1415926;
+    for (int f = f0; f < f1; f++)
+        for (int n = 0; n < N; n++) {
+            const float u1 = random_module(seed);
+            const float u2 = random_module(seed);
+            const float amp = std::sqrt(-2.0f * std::log(1.0f - u1));
+            const int c = cw ? cw[(size_t)n * F + f] : 0;
+            out[(size_t)n * F + f] = (float)((double)sigma * std::sin(two_pi * (double)u2) * (double)amp + 1.0 - (double)(2 * c));
+        }
+}
+} // namespace
+
+// The reference's generator is ONE serial stream; an LCG can be advanced k steps at once (seed * a^k mod m), so the frames are
+// cut into contiguous ranges, one per host thread, each of which starts from the stream state the serial loop would have at its
+// first frame: the same draws, the same host libm, the same bits as the serial loop (checked against the oracle's serial
+// generator by every test that uses this function), in 1/threads of the time.
+extern "C" int bldpc_awgn_channel_host(int seed[3], float sigma, float *out, const int *cw, int N, int F)
+{
+    if (!seed || !out || N <= 0 || F <= 0) return cldpc::fail(BLDPC_EINVAL, "bldpc_awgn_channel_host: bad argument");
+    bool jumpable = true; // the jump needs canonical states; any other int triple takes the serial loop as the reference would
+    for (int i = 0; i < 3; i++) jumpable = jumpable && seed[i] >= 0 && (unsigned)seed[i] < kM[i];
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int T = (int)std::min<long long>({(long long)(hw ? hw : 1), 16LL, (long long)F / 16, (long long)((size_t)N * F / 65536)});
+    if (!jumpable || T < 2) {
+        awgn_frames(seed, sigma, out, cw, N, F, 0, F);
+        return BLDPC_OK;
+    }
+    const int s0[3] = {seed[0], seed[1], seed[2]};
+    auto jumped = [&](int f, int *s) {
+        const unsigned long long k = 2ull * (unsigned long long)N * f;
+        for (int i = 0; i < 3; i++) s[i] = (int)(((unsigned long long)s0[i] * powmod(kA[i], k, kM[i])) % kM[i]);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) {
+        const int f0 = (int)((long long)F * t / T), f1 = (int)((long long)F * (t + 1) / T);
+        th.emplace_back([=]() {
+            int s[3];
+            jumped(f0, s);
+            awgn_frames(s, sigma, out, cw, N, F, f0, f1);
+        });
+    }
+    for (auto &x : th) x.join();
+    jumped(F, seed);
+    return BLDPC_OK;
+}
+
+namespace {
 // One thread per (frame f, run of kRun consecutive bits): jump the three LCGs to the first draw of the run
 // (draw index 2*(f*N + n0)), then step them as RandomModule does.  threadIdx.x runs along f: stores coalesce.
 constexpr int kRun = 32;

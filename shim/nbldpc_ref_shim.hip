@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/nbldpc.h"
@@ -232,15 +233,33 @@ void run_sim(const LDPCCode *H, AWGNChannel *AWGN, Simulation *SIM, const CCompl
         if (s.device_channel) {
             if (nbldpc_awgn_channel_device_sym(AWGN->seed, AWGN->sigma, b.d_tx, len, B, qam ? 0 : 1, b.d_rx, st)) die("AWGNChannel (device)");
         } else {
+            // the reference's own stream, frame after frame (Simulation.cpp:118-122).  It is ONE serial stream, but an LCG can be
+            // advanced k draws at once, so host threads each take a contiguous range of frames starting from the state the serial
+            // loop would have there: same draws, same host libm, same bits; AWGN->seed after every frame is kept for the stop rule.
             seeds_after.resize((size_t)3 * B);
-            std::vector<float> frame_rx((size_t)len * 2);
-            for (int f = 0; f < B; f++) { // the reference's own stream, frame after frame (Simulation.cpp:118-122)
-                if (nbldpc_awgn_channel_host_sym(AWGN->seed, AWGN->sigma, &tx[0].Real, len, frame_rx.data())) die("AWGNChannel_CPU");
-                memcpy(&seeds_after[(size_t)3 * f], AWGN->seed, 3 * sizeof(int));
-                if (qam) memcpy(b.h_rx + (size_t)f * len * 2, frame_rx.data(), (size_t)len * 8);
-                else
-                    for (int i = 0; i < len; i++) b.h_rx[(size_t)f * len + i] = frame_rx[2 * i]; // BPSK: Demodulate reads .Real only (LDPC_Decoder.cpp:142)
+            int probe[3] = {seed0[0], seed0[1], seed0[2]};
+            const bool jumpable = nbldpc_seed_jump(probe, 0) == NBLDPC_OK; // canonical LCG states only; else serial like the reference
+            const unsigned hw = std::thread::hardware_concurrency();
+            const int T = jumpable ? (int)std::max<long>(1, std::min<long>({(long)(hw ? hw : 1), 16L, (long)B / 8})) : 1;
+            auto gen = [&](int f0, int f1) {
+                int sd[3] = {seed0[0], seed0[1], seed0[2]};
+                if (f0 && nbldpc_seed_jump(sd, 4ull * (unsigned long long)len * f0)) die("nbldpc_seed_jump");
+                std::vector<float> frame_rx((size_t)len * 2);
+                for (int f = f0; f < f1; f++) {
+                    if (nbldpc_awgn_channel_host_sym(sd, AWGN->sigma, &tx[0].Real, len, frame_rx.data())) die("AWGNChannel_CPU");
+                    memcpy(&seeds_after[(size_t)3 * f], sd, 3 * sizeof(int));
+                    if (qam) memcpy(b.h_rx + (size_t)f * len * 2, frame_rx.data(), (size_t)len * 8);
+                    else
+                        for (int i = 0; i < len; i++) b.h_rx[(size_t)f * len + i] = frame_rx[2 * i]; // BPSK: Demodulate reads .Real only (LDPC_Decoder.cpp:142)
+                }
+            };
+            if (T < 2) gen(0, B);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; t++) th.emplace_back(gen, (int)((long)B * t / T), (int)((long)B * (t + 1) / T));
+                for (auto &x : th) x.join();
             }
+            memcpy(AWGN->seed, &seeds_after[(size_t)3 * (B - 1)], 3 * sizeof(int));
             HIP_OR_DIE(hipMemcpyAsync(b.d_rx, b.h_rx, (size_t)B * len * (qam ? 8 : 4), hipMemcpyHostToDevice, st), "Cannot copy the channel output, exit!");
         }
         int rc = qam ? nbldpc_demodulate_qam(g_code, b.d_rx, b.d_con, AWGN->sigma, B, b.d_Lch, st) : nbldpc_demodulate_bpsk(g_code, b.d_rx, AWGN->sigma, B, b.d_Lch, st);

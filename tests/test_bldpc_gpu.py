@@ -391,8 +391,16 @@ def _build_cpp(root, so_path, tmp_path, name, sources):
     return exe
 
 
+@pytest.fixture(scope="module")
+def bmain_exe(C, tmp_path_factory):
+    """tests/cpp/ref_main_style_sweep.cpp + shim/ldpc_ref_shim.hip linked against the library: built once per module."""
+    from cuda_ldpc_amd._lib import SO_PATH
+    root = os.path.dirname(os.path.dirname(SO_PATH))
+    return _build_cpp(root, SO_PATH, tmp_path_factory.mktemp("bmain"), "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+
+
 @pytest.mark.parametrize("as_written", [0, 1])
-def test_reference_main_style_sweep_cpp_harness(C, orc, tmp_path, as_written):
+def test_reference_main_style_sweep_cpp_harness(C, orc, bmain_exe, as_written):
     """A sweep written like the reference's main() (main.cu:114-160) drives Get_H, Transform_H, Simulation_GPU, Statistic and
     LDPC_Decoder_GPU with the reference's signatures and structs (shim/ldpc_ref_shim.hpp).  Every SNR point's counters equal
     a CPU replay of the same loop through the oracle; with the intended circulant table the shim reaches the fused kernel
@@ -400,7 +408,7 @@ def test_reference_main_style_sweep_cpp_harness(C, orc, tmp_path, as_written):
     import subprocess
     from cuda_ldpc_amd._lib import SO_PATH
     root = os.path.dirname(os.path.dirname(SO_PATH))
-    exe = _build_cpp(root, SO_PATH, tmp_path, "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+    exe = bmain_exe
     J, L, Z, F, maxIT = 4, 24, 96, 256, 50
     out = subprocess.check_output([exe, _path(J, L, Z), str(J), str(L), str(Z), str(F), str(maxIT), str(as_written), "3.0", "3.5", "0.2",
                                    "3", "512"]).decode()
@@ -427,7 +435,7 @@ def test_reference_main_style_sweep_cpp_harness(C, orc, tmp_path, as_written):
 
 
 @pytest.mark.parametrize("exit_mode", [2, 1, 0])
-def test_reference_main_style_sweep_fast_path(C, tmp_path, exit_mode):
+def test_reference_main_style_sweep_fast_path(C, bmain_exe, exit_mode):
     """The fast path through the binary drop-in boundary (bldpc_shim_configure_fast): the same main.cu-style C++ sweep with the
     device-side channel and bldpc_decode_statistic behind the reference-signature Simulation_GPU -- no host channel, no copy of D,
     no host loop.  Counters per point equal the Python mirror (cuda_ldpc_amd.simulation.Simulation_GPU) with the same switches:
@@ -436,7 +444,7 @@ def test_reference_main_style_sweep_fast_path(C, tmp_path, exit_mode):
     from cuda_ldpc_amd._lib import SO_PATH
     from cuda_ldpc_amd.simulation import Simulation_GPU
     root = os.path.dirname(os.path.dirname(SO_PATH))
-    exe = _build_cpp(root, SO_PATH, tmp_path, "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+    exe = bmain_exe
     J, L, Z, F, maxIT = 4, 24, 96, 4096, 50
     out = subprocess.check_output([exe, _path(J, L, Z), str(J), str(L), str(Z), str(F), str(maxIT), "0", "3.0", "3.3", "0.2", "20", "8192",
                                    "1", "1", str(exit_mode), "0"]).decode()
@@ -456,13 +464,13 @@ def test_reference_main_style_sweep_fast_path(C, tmp_path, exit_mode):
         snr = np.float32(np.float64(snr) + 0.2)
 
 
-def test_reference_main_style_sweep_fast_path_reproduces_the_committed_sweep(C, tmp_path):
+def test_reference_main_style_sweep_fast_path_reproduces_the_committed_sweep(C, bmain_exe):
     """Two Es/N0 points of profiles/r02c_sweep_binary_J4_L24_Z96_per_frame_exit.txt (sweep.py binary --device-channel --per-frame
     --batch 262144), count for count, from the C++ harness: 3.0 dB 262144 frames / 575 error frames, 3.2 dB 262144 / 56."""
     import subprocess
     from cuda_ldpc_amd._lib import SO_PATH
     root = os.path.dirname(os.path.dirname(SO_PATH))
-    exe = _build_cpp(root, SO_PATH, tmp_path, "ref_main_style_sweep", ["tests/cpp/ref_main_style_sweep.cpp", "shim/ldpc_ref_shim.hip"])
+    exe = bmain_exe
     out = subprocess.check_output([exe, _path(4, 24, 96), "4", "24", "96", "262144", "50", "0", "3.0", "3.3", "0.2", "50", "10000",
                                    "1", "1", "2", "1200"]).decode()
     rows = [ln.split() for ln in out.splitlines() if ln.startswith(" 3.")]

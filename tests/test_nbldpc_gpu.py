@@ -591,6 +591,12 @@ def test_reference_signature_shim_cpp_harness(nb, code, orc, tmp_path, method, t
         assert line == want, (line, want)
 
 
+@pytest.fixture(scope="module")
+def nb_main_exe(tmp_path_factory):
+    """tests/cpp/nb_ref_main_style_sweep.cpp + shim/nbldpc_ref_shim.hip linked against the library: built once per module."""
+    return _build_nb_main(tmp_path_factory.mktemp("nb_main"))
+
+
 def _build_nb_main(tmp_path):
     import shutil
     import subprocess
@@ -617,14 +623,14 @@ def _run_nb_main(exe, *args):
 
 
 @pytest.mark.parametrize("cpu_gpu", [1, 0])
-def test_reference_main_style_nb_sweep_cpp_harness(nb, code, ocode, orc, tmp_path, cpu_gpu):
+def test_reference_main_style_nb_sweep_cpp_harness(nb, code, ocode, orc, nb_main_exe, cpu_gpu):
     """The NB half of the drop-in boundary: a main() written like myNBLDPC/src/main.cu:14-268 -- Get_H, GFInitial,
     Get_CONSTELLATION, Modulate, the Eb/N0 loop with Simulation_GPU (CPU_GPU 1, the reference's default) or Simulation_CPU, all
     with the reference's signatures -- linked against shim/nbldpc_ref_shim.hip and the library only.  The shim decodes 64 frames
     per launch; per point, frames / error frames / symbol errors / Total_Iteration and the AWGN seeds equal a frame-by-frame
     replay of decode_once_* (Simulation.cpp:115-158) through the oracle, and the first 16 frames at 3 dB equal the
     reference's own dump (tests/golden/nb_ref_3dB.npz)."""
-    exe = _build_nb_main(tmp_path)
+    exe = nb_main_exe
     cwf = os.path.join(NB, "codeword_bds_gf64.txt")
     pts, frames, rows = _run_nb_main(exe, "BDS.576.288.GF.64.txt", cwf, 64, 4, 2, 0, cpu_gpu, 2.0, 3.01, 1.0, 6, 20, 64, 0, 0)
     assert len(pts) == 2 and len(rows) == 2  # 2.0 and 3.0 dB; one result row per finished point (Simulation.cpp:198,241)
@@ -653,27 +659,28 @@ def test_reference_main_style_nb_sweep_cpp_harness(nb, code, ocode, orc, tmp_pat
     assert int(pts[0][2]) >= 1000 and int(pts[0][3]) >= 50  # the reference's stop rule (define.h:52-53)
 
 
-@pytest.mark.parametrize("method,cpu_gpu", [(1, 1), (3, 0), (2, 1)])
-def test_nb_sweep_cpp_harness_fast_mode_equals_python_loop(nb, code, tmp_path, method, cpu_gpu):
+@pytest.mark.parametrize("method,cpu_gpu,least_err,least_frames", [(1, 1, 30, 1500), (3, 0, 30, 1500), (2, 1, 3, 48)])  # log-QSPA walks conf(64, 3): few frames
+def test_nb_sweep_cpp_harness_fast_mode_equals_python_loop(nb, code, nb_main_exe, method, cpu_gpu, least_err, least_frames):
     """The same harness with the device-side channel (cfg.device_channel = 1: no host loop, no upload) and the other
     decoder_method values: counters and seeds equal cuda_ldpc_amd.nb_simulation.Simulation_GPU on the same device channel
     (same draws, same device libm), whatever the two batch sizes are."""
     from cuda_ldpc_amd.nb_simulation import NBSim, Simulation_GPU
-    exe = _build_nb_main(tmp_path)
+    exe = nb_main_exe
     cwf = os.path.join(NB, "codeword_bds_gf64.txt")
     cw = np.loadtxt(cwf, dtype=np.int32)
-    pts, _, _ = _run_nb_main(exe, "BDS.576.288.GF.64.txt", cwf, 64, 4, 2, method, cpu_gpu, 2.5, 2.51, 1.0, 30, 1500, 1000, 1, 0)
+    pts, _, _ = _run_nb_main(exe, "BDS.576.288.GF.64.txt", cwf, 64, 4, 2, method, cpu_gpu, 2.5, 2.51, 1.0, least_err, least_frames, 1000, 1, 0)
     sigma = nb.sigma_of(2.5, code.rate)
     seed = np.array([173, 173, 173], np.int32)
     SIM = NBSim(2.5)
-    assert Simulation_GPU(code, seed, sigma, SIM, cw, batch=384, leastErrorFrames=30, leastTestFrames=1500, device_channel=True, decoder_method=method) == 1
+    assert Simulation_GPU(code, seed, sigma, SIM, cw, batch=384 if method != 2 else 32, leastErrorFrames=least_err, leastTestFrames=least_frames, device_channel=True,
+                          decoder_method=method) == 1
     assert [int(x) for x in pts[0][2:9]] == [SIM.num_Frames, SIM.num_Error_Frames, SIM.num_Error_Bits, SIM.Total_Iteration] + seed.tolist()
 
 
-def test_nb_simulation_gpu_refuses_layered_tmm_like_the_reference(nb, tmp_path):
+def test_nb_simulation_gpu_refuses_layered_tmm_like_the_reference(nb, nb_main_exe):
     """decode_once_gpu prints "unfinished" and exits for decoder_method 3 (Simulation.cpp:140-144); so does the shim's Simulation_GPU."""
     import subprocess
-    exe = _build_nb_main(tmp_path)
+    exe = nb_main_exe
     r = subprocess.run([exe, "BDS.576.288.GF.64.txt", os.path.join(NB, "codeword_bds_gf64.txt"), "64", "4", "2", "3", "1", "3.0", "3.01", "1.0", "5", "10",
                         "64", "0", "0"], cwd=NB, capture_output=True, text=True)
     assert r.returncode == 0 and "unfinished" in r.stdout and "POINT" not in r.stdout
