@@ -59,8 +59,8 @@ void awgn_frames(int *seed, float sigma, float *out, const int *cw, int N, int F
 
 // The reference's generator is ONE serial stream; an LCG can be advanced k steps at once (seed * a^k mod m), so the frames are
 // cut into contiguous ranges, one per host thread, each of which starts from the stream state the serial loop would have at its
-// first frame: the same draws, the same host libm, the same bits as the serial loop (checked against the oracle's serial
-// generator by every test that uses this function), in 1/threads of the time.
+// first frame: the same draws, the same host libm, the same bits as the serial loop (the tests compare with a serial CPU
+// generator), in 1/threads of the time.
 extern "C" int bldpc_awgn_channel_host(int seed[3], float sigma, float *out, const int *cw, int N, int F)
 {
     if (!seed || !out || N <= 0 || F <= 0) return cldpc::fail(BLDPC_EINVAL, "bldpc_awgn_channel_host: bad argument");
