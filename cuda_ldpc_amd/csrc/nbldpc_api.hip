@@ -16,6 +16,7 @@
 
 #include "common.hpp"
 #include "nbldpc_kernel.hpp"
+#include "nbldpc_pipe_kernel.hpp"
 #include "nbldpc_tmm_kernel.hpp"
 #include "nbldpc_wide_kernel.hpp"
 #include "nbldpc_hbm_kernel.hpp"
@@ -35,6 +36,8 @@ struct nbldpc_code {
     int zero_coeff = 0; // an edge with coefficient 0 exists (EMS only, see nbldpc_code_create)
     int persist_grid = 0; // k_nb_ems / k_nb_ems_wide: workgroups that fill the chip once (CUs x workgroups per CU)
     bool hbm = false;   // decoded by k_nb_ems_hbm (state in a global-memory workspace): LDS too small or rows heavier than kNbMaxW
+    int pipe_grid = 0;        // k_nb_ems2 (two frames in flight per workgroup): resident workgroups, 0 = kernel not offered for this code
+    size_t pipe_lds = 0;
     int tmm_grid[2] = {0, 0}; // k_nb_tmm<q, layered>: the same, per schedule (0 = flooding, 1 = layered), fixed at create time
     bool no_persist = false;  // NBLDPC_NO_PERSIST, read once at create time (tests / experiments): one workgroup per frame
     // Frame counters of the persistent kernels: a ring of kWorkSlots words, one per decode call in flight (the call zeroes its
@@ -279,6 +282,17 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)nb_kernel(q, dv), nb_threads(q), lds) == hipSuccess && occ > 0)
                 c->persist_grid = ncu * occ;
         }
+        // the two-frame pipeline (nbldpc_pipe_kernel.hpp): GF(64), column weights <= 2, no zero coefficient, the columns fit its A/S/B waves
+        const int ncw = (M * dc + 63) / 64;
+        if (!r && !hbm && have_cu && q == 64 && dv <= 2 && !c->zero_coeff && (nb_threads(q) / 64 - ncw) * kNbPipeCpw >= N && !getenv("NBLDPC_NO_PIPE")) {
+            const size_t pl = ((lds + 15) & ~(size_t)15) + nb_pipe_extra_lds(N);
+            int occ = 0;
+            if (pl <= 160 * 1024 && hipFuncSetAttribute((const void *)k_nb_ems2<64, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_nb_ems2<64, 1024>, 1024, pl) == hipSuccess && occ > 0) {
+                c->pipe_grid = ncu * occ;
+                c->pipe_lds = pl;
+            }
+        }
         for (int layered = 0; !r && c->tmm_ok && layered < 2; layered++) { // per-kernel attributes and grids once, not per decode call
             const size_t tl = tmm_lds_bytes(N, M, q, dv, dc, layered != 0);
             TmmKernel k = tmm_kernel(q, layered != 0);
@@ -338,6 +352,14 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         const hipError_t le = hipGetLastError();
         CLDPC_HIP(hipFreeAsync(ws, st), NBLDPC_EHIP);
         CLDPC_HIP(le, NBLDPC_EHIP);
+        return NBLDPC_OK;
+    }
+    if (c->pipe_grid > 0 && !c2v && B >= 2) {
+        // two frames in flight per workgroup, frames from a counter (k_nb_ems2); L_c2v is not offered there
+        a.work = next_work_slot(c);
+        CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
+        hipLaunchKernelGGL((k_nb_ems2<64, 1024>), dim3(std::min(c->pipe_grid, (B + 1) / 2)), dim3(1024), c->pipe_lds, st, a);
+        CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
         return NBLDPC_OK;
     }
     if (c->persist_grid > 0 && B > c->persist_grid && !c->no_persist) {

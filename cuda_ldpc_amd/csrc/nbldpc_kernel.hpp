@@ -72,19 +72,25 @@ __device__ __forceinline__ float nb_div12(float x)
     return (x == 0.0f || __builtin_isinf(x)) ? x : q;
 }
 
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ float nb_dpp_max(float v)
-{
-    const int x = __builtin_bit_cast(int, v);
-    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false)));
-}
+// Each butterfly step is ONE instruction, v_max_f32 with the DPP pattern on its first operand (through fmaxf and a separate
+// v_mov_b32_dpp the compiler emits five: copy, wait states, move, and two canonicalising maxima).  The two row broadcasts write
+// the rows their masks name and leave the others as they are; v_max_f32 returns one of its operands unchanged for the ordered
+// values met here (no NaN reaches a decision, see nb_ds_max).
 __device__ __forceinline__ float nb_wave_max(float v)
 {
-    v = nb_dpp_max<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
-    v = nb_dpp_max<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
-    v = nb_dpp_max<0x141, 0xf>(v); // row_half_mirror
-    v = nb_dpp_max<0x140, 0xf>(v); // row_mirror: every lane of a row holds the row's maximum
-    v = nb_dpp_max<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
-    v = nb_dpp_max<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t" // every lane of a row holds the row's maximum
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" // into rows 1 and 3
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" // into rows 2 and 3: lane 63 holds the maximum
+        : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 

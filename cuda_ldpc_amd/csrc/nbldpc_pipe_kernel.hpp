@@ -1,0 +1,349 @@
+// nbldpc_pipe_kernel.hpp -- k_nb_ems2: the fused GF(q) EMS decoder with TWO frames in flight per workgroup.
+//
+// Same arithmetic, same order, same bits as k_nb_ems (nbldpc_kernel.hpp; reference: myNBLDPC/src/LDPC_Decoder.cpp:172-359).  What
+// changes is WHEN things run.  k_nb_ems runs the phases of one frame back to back: variable nodes (A), syndrome (S), the
+// 192 sorts (B), then the check-node walk (C) -- 192 chains of ~1 260 DEPENDENT float additions (the reference's by-reference
+// running sum) on 3 of the 16 waves while 13 wait: 16.5 k of an iteration's 40 k cycles at one instruction every ~8.5 cycles per
+// SIMD (stamps in profiles/r03_nb_conflict_free_layout.txt; tools/dep_chain.hip: it is the addition latency, not the LDS).
+// A second frame cannot simply be made resident: one frame's sorted pairs (100 KB) and max arrays (48 KB) fill the CU's LDS.
+//
+// Here the workgroup has fixed roles -- the first NCW waves (3 for the BDS code) only ever walk check rows, the others
+// ("AB waves") do phases A, S, B -- and two frame slots that run half an iteration apart:
+//
+//     half-step h (slot s = h & 1 in its A/S/B half, slot c = 1 - s in its C half)
+//       stage 1   AB waves: store slot c's sorted pairs, kept in REGISTERS since its phase B, into the one `pairs` array
+//                 (slot s's pairs, which its walk read in the previous half-step, are dead); then A(s): c2v from the one set of
+//                 max arrays E (written by C(s) in the previous half-step), LLR, hard decision, v2c(s) -> registers
+//       -- barrier --
+//       stage 2   C waves: C(c): pairs -> E                      |  AB waves: S(s) (every wave for itself: no extra barrier),
+//                                                                 |            B(s): v2c(s) sorted in registers
+//       -- barrier --
+//
+// so one `pairs` array and one `E` array serve both frames (E is free once A(s) has read it; pairs is free once C has read it)
+// and the walk's latency chains run in the shadow of the other frame's sorts.  A frame whose syndrome is zero (or that has used
+// max_iter iterations) leaves in its S; its slot takes the next frame from the counter.  The channel vectors are re-read from
+// global memory every iteration (24 KB per frame, L2-resident) instead of living in registers: the registers hold v2c / the
+// sorted pairs.  Not offered here (k_nb_ems takes those calls): codes with a zero coefficient, column weights above 2, the
+// L_c2v state output.
+#pragma once
+#include "nbldpc_kernel.hpp"
+
+#ifndef NB_PIPE_PRIO
+#define NB_PIPE_PRIO 1 // experiments (0 = none): 1 = the sorting waves above the walking waves in stage 2, 2 = the walking waves above
+#endif
+
+namespace cldpc {
+
+constexpr int kNbPipeCpw = 8; // columns per AB wave (13 AB waves x 8 >= 96 columns)
+
+// extra LDS behind k_nb_ems's layout: the second slot's hard symbols and the slot words
+__host__ __device__ inline size_t nb_pipe_extra_lds(int N) { return (size_t)(N + 16) * sizeof(int); }
+
+template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int q = Q, DVM = 2, CPW = kNbPipeCpw, QP = q + 1, SW = 4, NEW = CPW * DVM; // NEW: edges per AB wave
+    static_assert(NEW % SW == 0, "whole groups of sorts");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = NT / 64;
+    const int N = a.N, M = a.M, dv = a.dv, dc = a.dc;
+    const int NE = N * dv, TC = M * dc, PST = nb_pair_stride(q);
+    const int NCW = (TC + 63) >> 6, NAB = nwaves - NCW; // walking waves, A/S/B waves
+    const bool is_c = wave < NCW;
+    const int abw = wave - NCW;
+    float *pairs = lds;                    // [NE][PST]
+    float *E = pairs + NE * PST;           // [TC][q + 1]
+    int *outs0 = reinterpret_cast<int *>(E + TC * QP);  // [N] slot 0
+    int *flag = outs0 + N;                 // [4] (layout of k_nb_ems up to here)
+    unsigned char *mulb = reinterpret_cast<unsigned char *>(flag + 4); // [q][q]
+    unsigned short *t_vn_w = reinterpret_cast<unsigned short *>(mulb + q * q); // [N]
+    unsigned short *t_vn_thr = t_vn_w + N;      // [N][dv]
+    unsigned short *t_vn_gf = t_vn_thr + NE;    // [N][dv]
+    unsigned short *t_cn_w = t_vn_gf + NE;      // [M]
+    unsigned short *t_cn_src = t_cn_w + M;      // [M][dc]
+    unsigned short *t_cn_gf = t_cn_src + TC;    // [M][dc]
+    unsigned short *t_cn_vn = t_cn_gf + TC;     // [M][dc]
+    unsigned char *t_elive = reinterpret_cast<unsigned char *>(t_cn_vn + TC); // [NE] (unused here; keeps the layout of k_nb_ems)
+    // (offsets, not integer-cast pointers: the stores below must stay LDS stores)
+    const int o1 = (int)((((reinterpret_cast<char *>(t_elive + NE) - reinterpret_cast<char *>(lds)) + 15) & ~15) / 4);
+    int *outs1 = reinterpret_cast<int *>(lds) + o1; // [N] slot 1
+    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] slot retired in this half-step; [4] pairs hold a sorted frame
+    for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
+    for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
+    for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
+    for (int i = tid; i < TC; i += NT) {
+        t_cn_src[i] = (unsigned short)a.cn_src[i]; t_cn_gf[i] = (unsigned short)a.cn_gf[i]; t_cn_vn[i] = (unsigned short)a.cn_vn[i];
+    }
+    for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
+    if (tid == 0) {
+        const int f = atomicAdd(a.work, 2); // the first two frames of this workgroup
+        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0;
+    }
+    __syncthreads();
+
+    // The two kinds of wave run two separate loops with the same sequence of barriers (and the same slot bookkeeping, derived from
+    // the same LDS words), so that the register allocation of the walk does not carry the A/S/B waves' long-lived arrays, and
+    // vice versa.
+    int frame0 = __builtin_amdgcn_readfirstlane(st[0]), frame1 = __builtin_amdgcn_readfirstlane(st[1]);
+#ifdef NB_STAMP
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    long long nhalf = 0;
+#define NB_PT(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define NB_PT(i)
+#endif
+    if (is_c) {
+        for (int h = 0;; h++) {
+            const int s = h & 1;
+            if (frame0 >= a.B && frame1 >= a.B) break; // the counter only grows: both slots are past the batch
+            NB_PT(0)
+            __syncthreads(); // ---- end of stage 1: slot c's sorted pairs are in `pairs` (st[4]), E has been read by A(s)
+            NB_PT(1)
+            if (NB_PIPE_PRIO == 2) __builtin_amdgcn_s_setprio(3);
+            if (__builtin_amdgcn_readfirstlane(st[4]) && tid < TC) { // C(c): check nodes (:272-303)
+                const int row = tid / dc, e = tid - row * dc, w = t_cn_w[row];
+                if (e < w) {
+                    switch (w) {
+                    case 2: nb_cn_update<2, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                    case 3: nb_cn_update<3, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                    case 4: nb_cn_update<4, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                    case 5: nb_cn_update<5, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                    case 6: nb_cn_update<6, Q>(a, t_cn_src, pairs, E, QP, row, e, tid); break;
+                    default: break;
+                    }
+                }
+            }
+            if (NB_PIPE_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+            NB_PT(2)
+            __syncthreads(); // ---- end of stage 2
+            NB_PT(3)
+#ifdef NB_STAMP
+            nhalf++;
+#endif
+            if (__builtin_amdgcn_readfirstlane(st[2 + s])) { // slot s retired in this half-step: its next frame
+                const int f = __builtin_amdgcn_readfirstlane(st[s]);
+                if (s) frame1 = f; else frame0 = f;
+            }
+        }
+#ifdef NB_STAMP
+        if (tid == 0 && blockIdx.x == 0 && a.LLR) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.LLR);
+            for (int i = 0; i < 4; i++) o[i] = tacc[i];
+            o[4] = (unsigned long long)nhalf;
+        }
+#endif
+        return;
+    }
+
+    const bool active = lane < q - 1;          // lanes 0..q-2 <-> field elements 1..q-1
+    const int sym = active ? lane + 1 : 0;     // lane q-1 carries element 0 (value 0, :250)
+    // per AB wave: its columns abw + ci * NAB, per column and edge the LDS offset of THIS lane's entry of the check thread's max
+    // array, E[thr][mul(sym, h)] (the graph does not change: one read per iteration instead of three dependent look-ups)
+    int evoff[CPW][DVM];
+    unsigned wmask = 0, cmask = 0; // bit ci*DVM + d: edge d of column ci exists; bit ci: the column exists
+#pragma unroll
+    for (int ci = 0; ci < CPW; ci++) {
+        const int colr = abw + ci * NAB, col = min(colr, N - 1);
+        const int w = t_vn_w[col];
+        if (colr < N) cmask |= 1u << ci;
+#pragma unroll
+        for (int d = 0; d < DVM; d++) {
+            const int dd = min(d, dv - 1);
+            evoff[ci][d] = t_vn_thr[col * dv + dd] * QP + mulb[sym * q + t_vn_gf[col * dv + dd]];
+            if (d < w && colr < N) wmask |= 1u << (ci * DVM + d);
+        }
+    }
+    wmask = __builtin_amdgcn_readfirstlane(wmask); // wave-uniform by construction; the compiler cannot know (they come out of LDS):
+    cmask = __builtin_amdgcn_readfirstlane(cmask); // as scalars, the tests below are scalar branches instead of EXEC masking
+    int it0 = 0, it1 = 0;
+    bool sorted0 = false, sorted1 = false; // the slot's sorted pairs sit in sval / ssym
+    float sval[NEW];                       // sorted values of this wave's edges (lane <-> sorted position)
+    unsigned ssym[NEW / 4];                // their premultiplied symbols mul(symbol, h), one byte each
+    const uint32_t kmw = nb_keepmax_word(lane);
+    // channel vectors of the columns of this wave for the slot whose phase A comes next: loaded one half-step ahead (global
+    // memory, ~1 us away), so that the loads fly during the sorts of the other slot
+    float lch[CPW];
+    auto load_lch = [&](int frame) {
+        const float *Lch = a.Lch + (size_t)min(frame, a.B - 1) * N * (q - 1);
+        int lo = lane;
+        asm volatile("" : "+v"(lo)); // opaque: the loads are issued here
+#pragma unroll
+        for (int ci = 0; ci < CPW; ci++) lch[ci] = active ? Lch[min(abw + ci * NAB, N - 1) * (q - 1) + lo] : 0.0f;
+    };
+    load_lch(frame0);
+
+    const int abw_fixed = abw;
+    for (int h = 0;; h++) {
+        const int s = h & 1;
+        const int frame_s = s ? frame1 : frame0, frame_c = s ? frame0 : frame1;
+        if (frame_s >= a.B && frame_c >= a.B) break;
+        const bool act_s = frame_s < a.B;
+        int abw = abw_fixed; // opaque per half-step: left alone the compiler hoists every column's addresses out of the loop and spills ~150 scalars
+        asm volatile("" : "+s"(abw));
+        int *outs = outs0 + (s ? (int)(outs1 - outs0) : 0);
+        float v2c[NEW];
+        NB_PT(3)
+        // ---- stage 1 ----------------------------------------------------------------------------------------------------
+        {
+            const bool have = s ? sorted0 : sorted1; // slot c was sorted in the previous half-step
+            if (have) {
+#pragma unroll
+                for (int j = 0; j < NEW; j++) {
+                    const int ci = j / DVM, d = j % DVM;
+                    if ((wmask >> j) & 1u) {
+                        float2 pr;
+                        pr.x = sval[j];
+                        pr.y = __int_as_float((int)((ssym[j >> 2] >> (8 * (j & 3))) & 0xffu) << 2); // byte offset into the thread's max array
+                        *reinterpret_cast<float2 *>(pairs + ((abw + ci * NAB) * dv + d) * PST + 2 * lane) = pr;
+                    }
+                }
+            }
+            if (abw == 0 && lane == 0) {
+                st[4] = have ? 1 : 0;
+                st[2 + s] = 0; // "slot s retired": set in this half-step's S, read by every wave after the second barrier
+            }
+            if (s) sorted0 = false; else sorted1 = false;
+            if (act_s) {
+                const int it = (s ? it1 : it0) + 1;
+                if (s) it1 = it; else it0 = it;
+                const bool fresh = it == 1; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+                float *LLRo = a.LLR ? a.LLR + (size_t)frame_s * N * (q - 1) : nullptr;
+                // all the max-array entries of this wave's columns in one batch of reads (a frame's first iteration: L_c2v = 0,
+                // made by reading nothing -- (0 - 0) / 1.2 == +0 goes through the same arithmetic, no branch)
+                float evs[NEW];
+#pragma unroll
+                for (int j = 0; j < NEW; j++) evs[j] = E[evoff[j / DVM][j % DVM]];
+#pragma unroll
+                for (int j = 0; j < NEW; j++) evs[j] = fresh ? 0.0f : evs[j];
+#pragma unroll
+                for (int ci = 0; ci < CPW; ci++) {
+                    const int col = min(abw + ci * NAB, N - 1);
+                    float llr = lch[ci];
+                    float c2[DVM];
+#pragma unroll
+                    for (int d = 0; d < DVM; d++) {
+                        const float ev = evs[ci * DVM + d];
+                        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), Q - 1));
+                        const float c = nb_div12(ev - e0); // :309, double division
+                        const bool on = (wmask >> (ci * DVM + d)) & 1u;
+                        c2[d] = on ? c : 0.0f;
+                        llr = on ? llr + c : llr; // :208-213, ascending d
+                    }
+                    // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
+                    const float v = active ? llr : -__builtin_inff();
+                    const float mx = nb_wave_max(v);
+                    const unsigned long long eq = __ballot(active && v == mx);
+                    const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
+                    if ((cmask >> ci) & 1u) {
+                        if (lane == 0) outs[col] = dec;
+                        if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
+                    }
+#pragma unroll
+                    for (int d = 0; d < DVM; d++) v2c[ci * DVM + d] = active ? llr - c2[d] : 0.0f; // :241-251 (element 0: value 0)
+                }
+            }
+        }
+        NB_PT(0)
+        __syncthreads();
+        NB_PT(1)
+        // ---- stage 2 ----------------------------------------------------------------------------------------------------
+        if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+        load_lch(frame_c); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
+        if (act_s) {
+            // S: syndrome (:218-238), by every AB wave for itself (lane <-> check row, 64 rows per round): no barrier of its own
+            bool bad = false;
+            for (int r0 = 0; r0 < M; r0 += 64) {
+                const int r = r0 + lane;
+                int sy = 0;
+                if (r < M)
+                    for (int i = 0; i < t_cn_w[r]; i++) sy ^= mulb[outs[t_cn_vn[r * dc + i]] * q + t_cn_gf[r * dc + i]];
+                bad = bad || (__ballot(sy != 0) != 0ull);
+            }
+            const int it = s ? it1 : it0;
+            if (!bad || it == a.max_iter) { // the frame leaves: zero syndrome (:232-238, iter_number-- first) or maxIT iterations used
+                for (int i = abw * 64 + lane; i < N; i += NAB * 64) a.out[(size_t)frame_s * N + i] = outs[i];
+                if (abw == 0 && lane == 0) {
+                    a.iters[frame_s] = bad ? it : it - 1;
+                    a.ok[frame_s] = bad ? 0 : 1;
+                    st[s] = atomicAdd(a.work, 1);
+                    st[2 + s] = 1;
+                }
+                if (s) it1 = 0; else it0 = 0;
+            } else {
+                // B: stable descending sort of every v2c vector (:17-36, :253-269), as in k_nb_ems but from and to registers
+#pragma unroll
+                for (int g = 0; g < NEW / SW; g++) {
+                    uint32_t khi[SW], k32[SW];
+#pragma unroll
+                    for (int i = 0; i < SW; i++) {
+                        const uint32_t b = __float_as_uint(v2c[g * SW + i] + 0.0f); // +0.0f folds -0 onto +0 (they compare equal)
+                        khi[i] = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
+                        k32[i] = (khi[i] & 0xffffffc0u) | (63u - (unsigned)lane);
+                    }
+                    nb_bitonic_sort32<64>(k32, kmw);
+                    int idx[SW];
+                    bool amb = false; // two neighbours of the sorted order agree in the 26 bits the short keys carry
+#pragma unroll
+                    for (int i = 0; i < SW; i++) {
+                        idx[i] = 63 - (int)(k32[i] & 63u);
+                        const uint32_t nk = (uint32_t)__builtin_amdgcn_update_dpp((int)k32[i], (int)k32[i], 0x130, 0xf, 0xf, false); // wave_shl:1
+                        amb = amb || (__ballot(((k32[i] ^ nk) < 64u) && lane < 63) != 0ull);
+                    }
+                    // No such pair: all 64 short keys differ above their index bits, so their order IS the order of the full
+                    // (value, index) keys.  Otherwise verify the permutation against the full keys, as k_nb_ems does.
+                    if (amb) {
+                        uint32_t img[SW];
+                        bool redo = false;
+#pragma unroll
+                        for (int i = 0; i < SW; i++) img[i] = (uint32_t)__shfl((int)khi[i], idx[i], 64);
+#pragma unroll
+                        for (int i = 0; i < SW; i++) {
+                            const uint32_t nimg = (uint32_t)__builtin_amdgcn_update_dpp((int)img[i], (int)img[i], 0x130, 0xf, 0xf, false);
+                            const int nidx = __builtin_amdgcn_update_dpp(idx[i], idx[i], 0x130, 0xf, 0xf, false);
+                            const bool in_order = img[i] > nimg || (img[i] == nimg && idx[i] < nidx);
+                            redo = redo || (__ballot(!in_order && lane < 63) != 0ull);
+                        }
+                        if (redo) { // two values that differ only in their low 6 bits: this group again, on the full keys (wave-uniform branch)
+                            uint32_t klo[SW];
+#pragma unroll
+                            for (int i = 0; i < SW; i++) klo[i] = 63u - (unsigned)lane;
+                            nb_bitonic_sort<64, SW>(khi, klo);
+#pragma unroll
+                            for (int i = 0; i < SW; i++) idx[i] = 63 - (int)klo[i];
+                        }
+                    }
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int i = 0; i < SW; i++) {
+                        const int j = g * SW + i, ci = j / DVM, d = j % DVM;
+                        const int edge = min(abw + ci * NAB, N - 1) * dv + min(d, dv - 1);
+                        const int symk = (idx[i] < q - 1) ? idx[i] + 1 : 0; // idx: original position of the element that belongs at position `lane`
+                        sval[j] = __shfl(v2c[j], idx[i], 64);
+                        pk |= (unsigned)mulb[symk * q + t_vn_gf[edge]] << (8 * i); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
+                    }
+                    ssym[g] = pk;
+                }
+                if (s) sorted1 = true; else sorted0 = true;
+            }
+        }
+        if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        NB_PT(2)
+        __syncthreads();
+#ifdef NB_STAMP
+        nhalf++;
+#endif
+        if (__builtin_amdgcn_readfirstlane(st[2 + s])) { // slot s retired in this half-step: its next frame
+            const int f = __builtin_amdgcn_readfirstlane(st[s]);
+            if (s) frame1 = f; else frame0 = f;
+        }
+    }
+#ifdef NB_STAMP
+    if (abw == 0 && lane == 0 && blockIdx.x == 0 && a.LLR) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.LLR) + 8;
+        for (int i = 0; i < 4; i++) o[i] = tacc[i];
+        o[4] = (unsigned long long)nhalf;
+    }
+#endif
+}
+
+} // namespace cldpc

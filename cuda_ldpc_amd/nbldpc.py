@@ -100,7 +100,8 @@ def Decoding_EMS(code, L_ch, EMS_Nm=2, EMS_Nc=2, maxIT=20, maxdc=0, want_state=F
     """Decoding_EMS (LDPC_Decoder.cpp:172-317) for a batch.
 
     L_ch: CUDA float32 [B, N, q-1].  Returns dict(DecodeOutput [B,N] int32, iter_number [B], ok [B],
-    LLR [B,N,q-1] | None, L_c2v [B,M,dc,q-1] | None), all on the device."""
+    LLR [B,N,q-1] | None, L_c2v [B,M,dc,q-1] | None), all on the device.  want_state: True = both state arrays,
+    "llr" = VN[].LLR only (the two-frame pipeline kernel does not produce CN[].L_c2v: a call that asks for it runs on k_nb_ems)."""
     if not (L_ch.is_cuda and L_ch.dtype == torch.float32 and L_ch.is_contiguous()):
         raise ValueError("L_ch must be a contiguous CUDA float32 tensor")
     if L_ch.dim() != 3 or L_ch.shape[1] != code.N or L_ch.shape[2] != code.q - 1:
@@ -110,7 +111,7 @@ def Decoding_EMS(code, L_ch, EMS_Nm=2, EMS_Nc=2, maxIT=20, maxdc=0, want_state=F
     iters = torch.empty(B, dtype=torch.int32, device=dev)
     ok = torch.empty(B, dtype=torch.int32, device=dev)
     LLR = torch.empty((B, code.N, code.q - 1), dtype=torch.float32, device=dev) if want_state else None
-    c2v = torch.empty((B, code.M, code.dc, code.q - 1), dtype=torch.float32, device=dev) if want_state else None
+    c2v = torch.empty((B, code.M, code.dc, code.q - 1), dtype=torch.float32, device=dev) if (want_state and want_state != "llr") else None
     st = c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
     _check(lib.nbldpc_ems_decode_batch(code._h, _dev(L_ch), B, EMS_Nm, EMS_Nc, maxIT, maxdc, _dev(out), _dev(iters), _dev(ok),
                                        _dev(LLR), _dev(c2v), st), "Decoding_EMS")

@@ -814,3 +814,49 @@ def test_persistent_nb_kernels_equal_one_workgroup_per_frame(nb, orc, monkeypatc
         assert int(a["iter_number"][f]) == w["it"] and int(a["ok"][f]) == w["ok"] and np.array_equal(a["DecodeOutput"][f].cpu().numpy(), w["out"])
         assert np.array_equal(a["LLR"][f].cpu().numpy().view(np.uint32), w["LLR"].view(np.uint32))
 
+
+# ---- k_nb_ems2: two frames in flight per workgroup (nbldpc_pipe_kernel.hpp); every call without the L_c2v output takes it ----------
+@pytest.mark.parametrize("snr", [2, 3, 5])
+def test_pipeline_kernel_matches_reference_dump(nb, code, orc, snr):
+    """The reference's own channel samples and outputs (Decoding_EMS of the reference, tests/golden/nb_ref_*.npz) through the
+    two-frame pipeline kernel: symbols, iteration counts, return flags and the bits of the final LLR of all 16 frames."""
+    g = np.load(os.path.join(GOLDEN, "nb_ref_%ddB.npz" % snr))
+    Lch = nb.Demodulate(code, torch.from_numpy(g["rx"]).cuda(), float(g["sigma"]))
+    r = nb.Decoding_EMS(code, Lch, 2, 2, int(g["maxit"]), want_state="llr")
+    torch.cuda.synchronize()
+    assert r["L_c2v"] is None
+    assert np.array_equal(r["iter_number"].cpu().numpy(), g["it"]) and np.array_equal(r["ok"].cpu().numpy(), g["ok"])
+    assert np.array_equal(r["DecodeOutput"].cpu().numpy(), g["out"])
+    LLR = r["LLR"].cpu().numpy()
+    for fr in range(LLR.shape[0]):
+        assert orc.fold_hash(LLR[fr]) == int(g["LLR_hash"][fr]), "LLR frame %d" % fr
+
+
+@pytest.mark.parametrize("B,snr,maxit", [(3001, 2.8, 20), (2, 3.0, 20), (3, 1.0, 5), (700, 2.0, 20), (513, 6.0, 20), (640, 3.2, 1)])
+def test_pipeline_kernel_equals_the_one_frame_kernel(nb, code, monkeypatch, B, snr, maxit):
+    """k_nb_ems2 against k_nb_ems (a code object created under NBLDPC_NO_PIPE=1) on whole batches: symbols, iteration counts,
+    flags and final LLR bits -- odd batches, two frames, frames that all fail, frames that all pass at once, maxIT 1."""
+    mul, _, _ = nb.GFInitial(64, os.path.join(NB, "GF", "Arith.Table.GF.64.txt"))
+    monkeypatch.setenv("NBLDPC_NO_PIPE", "1")
+    plain = nb.NBCode(os.path.join(NB, "BDS.576.288.GF.64.txt"), mul)
+    monkeypatch.delenv("NBLDPC_NO_PIPE")
+    cw = np.loadtxt(os.path.join(NB, "codeword_bds_gf64.txt"), dtype=np.int32)
+    seed = np.array([173, 173, 173], np.int32)
+    sigma = nb.sigma_of(snr, code.rate)
+    Lch = nb.Demodulate(code, nb.AWGNChannel_GPU(seed, sigma, code, torch.from_numpy(cw).cuda(), B), sigma)
+    if B == 700:
+        Lch = torch.round(Lch)  # ties everywhere: the sort's repeat path, first-maximum decisions
+    a = nb.Decoding_EMS(code, Lch, 2, 2, maxit, want_state="llr")
+    b = nb.Decoding_EMS(plain, Lch, 2, 2, maxit, want_state="llr")
+    torch.cuda.synchronize()
+    for k in ("DecodeOutput", "iter_number", "ok"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["LLR"].view(torch.int32), b["LLR"].view(torch.int32))
+    its = a["iter_number"].cpu().numpy()
+    if B == 3001:
+        assert len(set(its.tolist())) > 5
+    c = nb.Decoding_EMS(code, Lch, 2, 2, maxit)  # no state outputs at all: the production call
+    torch.cuda.synchronize()
+    for k in ("DecodeOutput", "iter_number", "ok"):
+        assert torch.equal(a[k], c[k]), k
+
