@@ -69,9 +69,19 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
     auto y_lc = [&](int z) -> float { // y[LC*Z + tid + z * TPB]
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, tid * 4, (lcbase + z * TPB) * 4, 0));
     };
-    auto recon = [&](float a1, float a2, unsigned ww, int p) -> float {
-        const float mag = ((int)(ww >> 27) == p) ? a2 : a1;
-        return u2f(f2u(mag) | ((ww >> (WCS - 1 - p)) << 31));
+    // R_p of a check from its compressed state: magnitude m2 on the edge that held the minimum, m1 elsewhere, and the edge's sign bit.
+    // `oh` = 1 << (index of that edge), formed once per state and phase: the select is then a sign-extended bit (v_bfe_i32) and a
+    // bit-field insert (v_bfi_b32), two full-rate instructions, where a compare + v_cndmask_b32 are two of the half-rate class
+    // (profiles/r02_micro_rates.txt).  Same bits.  PON J12_L69_Z256: 357 -> 373 k codewords/s.  (k_qcr2 keeps the compare form: there the
+    // same change costs registers -- 155 -> 168 VGPRs with spills -- and J15_L30_Z1280 fell from 212 to 178 k codewords/s.)
+    auto recon = [&](float a1, float a2, unsigned ww, unsigned oh, int p) -> float {
+        // (inline asm: left to itself the compiler rebuilds a compare and a v_cndmask_b32 out of the C form)
+        unsigned sel, mag, r;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(oh), "n"(p));               // all ones on the edge of the minimum
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(mag) : "v"(sel), "v"(a2), "v"(a1));      // (m2 & sel) | (m1 & ~sel)
+        const unsigned sh = ww << (31 - (WCS - 1 - p));                                 // the edge's sign bit at bit 31
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(0x80000000u), "v"(sh), "v"(mag)); // (sh & sign) | (mag & ~sign)
+        return u2f(r);
     };
     // byte address of the S value behind row slot m for circulant position t: column base + (t + shift) mod Z
     auto s_addr = [&](unsigned m, int t) -> int {
@@ -125,9 +135,10 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
                 float n1 = __builtin_inff(), n2 = __builtin_inff();
                 unsigned signs = 0;
                 int idx = 0;
+                const unsigned oh = 1u << (w2[j][z] >> 27); // the edge that held the previous minimum, one-hot (recon)
 #pragma unroll
                 for (int p = 0; p < WCS; p++) {
-                    float q = Sv[z][p] - recon(m1[j][z], m2[j][z], w2[j][z], p); // Q = S - R (:206-209)
+                    float q = Sv[z][p] - recon(m1[j][z], m2[j][z], w2[j][z], oh, p); // Q = S - R (:206-209)
                     if (p >= MINW) q = ((m[p] >> 21) & 1u) ? __builtin_inff() : q;
                     const float aq = __builtin_fabsf(q);
                     idx = (aq < n1) ? p : idx; // first edge holding the minimum (:298-305)
@@ -180,11 +191,12 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
                     lds_ld<1>(sv, lds, va[p]);
                     acc[p] = sv[0];
                 }
-                acc0[z] += recon(m1[j][z], m2[j][z], w2[j][z], 0); // slot 0 = column LC: this thread's own variable
+                const unsigned oh = 1u << (w2[j][z] >> 27);
+                acc0[z] += recon(m1[j][z], m2[j][z], w2[j][z], oh, 0); // slot 0 = column LC: this thread's own variable
 #pragma unroll
                 for (int p = 1; p < WCS; p++) {
                     const float prev = ((m[p] >> 19) & 1u) ? 0.0f : acc[p]; // a column's first edge starts from 0
-                    const float sv[1] = {prev + recon(m1[j][z], m2[j][z], w2[j][z], p)};
+                    const float sv[1] = {prev + recon(m1[j][z], m2[j][z], w2[j][z], oh, p)};
                     lds_st<1>(lds, va[p], sv);
                 }
                 __builtin_amdgcn_sched_barrier(0);
