@@ -123,17 +123,21 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
 #pragma unroll
             for (int z = 0; z < NZ; z++) {
                 float n1 = __builtin_inff(), n2 = __builtin_inff();
-                unsigned signs = 0;
-                int idx = 0;
+                unsigned signs = 0, lower = 0;
 #pragma unroll
                 for (int p = 0; p < WCS; p++) {
                     const float q = Sv[z][p] - recon(m1[j][z], m2[j][z], w2[j][z], p); // Q = S - R (:206-209); a pad slot: +inf
                     const float aq = __builtin_fabsf(q);
-                    idx = (aq < n1) ? p : idx; // first edge holding the minimum (:298-305)
+                    // "this edge lowered the running minimum" as a bit per edge: the sign of |q| - n1 (equal values give +0, inf - inf the
+                    // positive default NaN), two full-rate instructions where compare + v_cndmask_b32 into an index are two of the half-rate class
+                    lower = __builtin_amdgcn_alignbit(lower, f2u(aq - n1), 31);
                     n2 = __builtin_amdgcn_fmed3f(n1, n2, aq);
                     n1 = __builtin_fminf(n1, aq);
                     signs = __builtin_amdgcn_alignbit(signs, f2u(q), 31); // (signs << 1) | sign(q)
                 }
+                // first edge holding the minimum (:298-305) = the LAST edge that lowered it = the lowest set bit (edge p at bit WCS-1-p;
+                // no edge below +inf: edge 0, as the index form starts from)
+                const int idx = WCS - 1 - (int)__builtin_ctz(lower | (1u << (WCS - 1)));
                 // R_p = Sign[25]*Sign[p] * magnitude: output sign bit p = parity of all signs XOR sign p
                 if (__builtin_popcount(signs) & 1) signs ^= (1u << WCS) - 1u;
                 m1[j][z] = n1; m2[j][z] = n2;
