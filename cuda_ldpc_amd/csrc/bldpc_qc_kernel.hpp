@@ -295,13 +295,15 @@ __global__ __launch_bounds__(256) void k_expand_bits(const unsigned *bits, int *
 
 // ---------------------------------------------------------------------------------------------
 // Compressed-state kernel, see bldpc_qcc_kernel.hpp.  LDS: mm float2[M] | w2 uint[M] | S float[(L+1)*Z] | flag.
-template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_qcc(QcArgs a)
+// PERSIST (per-frame exit only): the grid fills the chip once and a workgroup takes frame after frame of its XCD from the counter
+// a.work[xcd], as k_qc2p / k_qcr2<PERSIST> do (frames leave after 1 ... max_iter iterations: one workgroup per frame leaves the CUs far apart)
+template <typename GM, bool HIST, bool PERSIST = false> __global__ __launch_bounds__(GM::TPB) void k_qcc(QcArgs a)
 {
     constexpr int Z = GM::Z, U = GM::U, G = GM::G, CPT = GM::CPT, WCS = GM::WCS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int chunk = (a.nWG + 7) >> 3; // XCD-aware workgroup id, see k_qc
-    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (wg >= a.nWG) return;
+    int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (!PERSIST && wg >= a.nWG) return;
     const int J = a.J, L = a.L, M = J * Z, N = L * Z, F = a.F;
     const int tid = threadIdx.x;
     const int g = __builtin_amdgcn_readfirstlane(tid / U); // wave-uniform
@@ -311,11 +313,20 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
     // check states 0 .. M-1, then Z states that stay zero (R = +0: what the padding entries of a column's edge list add)
     const int off_w2 = (M + Z) * 8, off_S = (M + Z) * 12;
     int *lds_flag = reinterpret_cast<int *>(lds + off_S + (L + 1) * Z * 4);
-    const int f = wg; // one frame per workgroup
     // per-edge tables, wave-uniform; read through the constant address space: scalar loads whatever else the kernel stores
     typedef __attribute__((address_space(4))) const unsigned qcc_cu32;
     const qcc_cu32 *cmeta = (const qcc_cu32 *)a.cn_meta; // [J][WCS] row slots, then [J] row weights
     const qcc_cu32 *vmeta = (const qcc_cu32 *)a.vn_meta; // [L][WVS] column edges, padded to a multiple of 2 with zero-state entries
+    for (;;) { // (one pass unless PERSIST)
+    if (PERSIST) {
+        const int xcd = (int)(blockIdx.x & 7);
+        if (tid == 0) lds_flag[2] = atomicAdd(&a.work[xcd], 1);
+        __syncthreads();
+        const int ord = __builtin_amdgcn_readfirstlane(lds_flag[2]);
+        if (ord >= chunk || xcd * chunk + ord >= a.nWG) break;
+        wg = xcd * chunk + ord;
+    }
+    const int f = wg; // one frame per workgroup
 
     // ---- prologue -----------------------------------------------------------------------------------------
     for (int j = g; j < J + 1; j += G)
@@ -477,6 +488,9 @@ template <typename GM, bool HIST> __global__ __launch_bounds__(GM::TPB) void k_q
             if (HIST && a.per_frame) a.iters[f] = last;
         }
     }
+    if (!PERSIST) break;
+    __syncthreads(); // the states, S, the flags and the frame word are reused by the next frame
+    } // next frame
 }
 
 #include "bldpc_qcr_kernel.hpp" // k_qcr: check states in registers, S in LDS (long blocks)
@@ -530,7 +544,7 @@ inline const QcVariant *qc_variants(int *count)
      k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow", 0, 0, 0, k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>},
 #define XC(Z, U, G, CPT, WCS)                                                                              \
     {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
-     k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0},
+     k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, true, true>},
 #define XR(J, L, Z, TPB, WCS, MINW, YB)                                                                     \
     {1, J, L, Z, WCS, 31, 0, MINW, TPB, 0, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, false>,               \
      k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true>, "regstate", 0, 0, 1, k_qcr<QcrGeom<J, L, Z, TPB, WCS, MINW, YB>, true, true>},

@@ -827,6 +827,7 @@ def test_batch_global_when_a_frame_loses_its_flag_again(C, orc, snr, length, s0,
 # ---- the persistent-workgroup instantiations (frames from per-XCD counters) are only reached by LARGE batches ------------------------
 PERSIST_CODES = [("J4_L24_Z96_BlockH.txt", 4, 24, 96, 3.0, 8192, "halfrow"),     # k_qc2p: grid 4096 pairs > 512 resident workgroups
                  ("J32_L64_Z64_BlockH.txt", 32, 64, 64, -0.6, 4096, "row"),      # k_qcp
+                 ("J10_L60_Z160_BlockH.txt", 10, 60, 160, 2.9, 2048, "compressed"),  # k_qcc<PERSIST>
                  ("PON_LDPC.txt", 12, 69, 256, 2.5, 2048, "regs"),               # k_qcr<PERSIST>
                  ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, -0.8, 1024, "regs")] # k_qcr2<PERSIST>
 
