@@ -272,7 +272,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         hipError_t e = hipSuccess;
         // the attribute belongs to the kernel, not to this code: set it to the CU's whole LDS once and for all, so that
         // creating a second code with a smaller state never lowers the cap under the first one
-        if (hbm) e = hipFuncSetAttribute((const void *)k_nb_ems_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256); // GF(256) table
+        if (hbm) e = hipFuncSetAttribute((const void *)k_nb_ems_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); // GF table + the max arrays of one pass (the kernel has two static words too)
         else e = hipFuncSetAttribute((const void *)nb_kernel(q, dv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) r = fail(NBLDPC_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         int dev = 0, ncu = 0;
@@ -348,7 +348,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         a.ws_stride = slot;
         a.work = next_work_slot(c);
         CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
-        hipLaunchKernelGGL(k_nb_ems_hbm, dim3(slots), dim3(kNbHbmThreads), (size_t)c->q * c->q, st, a);
+        hipLaunchKernelGGL(k_nb_ems_hbm, dim3(slots), dim3(kNbHbmThreads), nb_hbm_lds_bytes(c->q), st, a);
         const hipError_t le = hipGetLastError();
         CLDPC_HIP(hipFreeAsync(ws, st), NBLDPC_EHIP);
         CLDPC_HIP(le, NBLDPC_EHIP);

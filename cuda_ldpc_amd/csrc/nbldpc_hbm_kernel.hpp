@@ -5,7 +5,12 @@
 // per frame) instead of LDS, the graph tables read from global memory, and the check-node walk the reference's recursion
 // (myNBLDPC/src/LDPC_Decoder.cpp:319-359) executed literally -- an explicit stack, any row weight, any (Nm, Nc) -- rather than a
 // program unrolled per row weight.  Same arithmetic in the same order as the reference's Decoding_EMS (:172-317), so the same bits.
-// A completeness path: nothing here is tuned beyond keeping every phase parallel over the workgroup.
+// Round 3: the walk no longer steps through the workspace.  A (row, edge) thread keeps its max array in LDS (the workgroup walks
+// the check threads in chunks of as many as fit) and, for the two heavy-row shapes of the reference's matrix set -- GF(16) rows
+// of weight 21 (Tanner_74_9_Z128_GF16.txt) and GF(256) rows of weight 12 (LDPC_N576_K480_GF256_exp.txt) -- runs the straight-line
+// (and 20: the Tanner code has both) -- walk of the fused kernels (nb_t0 / nb_t1 / nb_conf, nbldpc_kernel.hpp) instantiated for that weight: the first two sorted pairs
+// of every neighbour in registers, the others prefetched a batch ahead of the float chain, so that a step is a dependent addition
+// (~8.5 cycles), not a dependent L2 load (~1 us).  Other row weights keep the explicit-stack walk, with the max array in LDS.
 //
 // Workspace slot (floats): v2c[NE][q] | pairs[NE][2q] (value, premultiplied symbol) | E[M*dc][q] (EMS_L_c2v) | LLR[N][q-1] | outs[N]
 #pragma once
@@ -14,7 +19,11 @@
 namespace cldpc {
 
 constexpr int kNbHbmMaxDc = 64;
-constexpr int kNbHbmThreads = 1024;
+constexpr int kNbHbmThreads = 512; // 256 VGPRs per thread: the weight-21 walk keeps 100 values of its 20 neighbours in registers
+
+// check threads walked per pass: their max arrays (q + 1 floats each, odd stride) share the LDS with the GF table
+__host__ __device__ inline int nb_hbm_chunk(int q) { return (int)min((size_t)kNbHbmThreads, ((size_t)160 * 1024 - 256 - (size_t)q * q) / ((size_t)(q + 1) * 4)); }
+__host__ __device__ inline size_t nb_hbm_lds_bytes(int q) { return (((size_t)q * q + 15) & ~(size_t)15) + (size_t)nb_hbm_chunk(q) * (q + 1) * 4; }
 
 __host__ __device__ inline size_t nb_hbm_slot_floats(int N, int M, int q, int dv, int dc)
 {
@@ -25,6 +34,7 @@ __host__ __device__ inline size_t nb_hbm_slot_floats(int N, int M, int q, int dv
 // ConstructConf(Nm, Nc, begin = 0, except = e) of LDPC_Decoder.cpp:319-359 for one (row, edge): the depth-first walk over the
 // row's other positions in ascending order, `sumNonLLR` carried through additions and subtractions exactly as the reference's
 // by-reference recursion carries it (the drift is part of the result), `k` of every open level on an explicit stack.
+// (symbols arrive premultiplied by 4, as byte offsets into the max array: the form the straight-line walk consumes)
 __host__ __device__ inline void nb_hbm_conf(const float *pairs, const int *cn_src_row, int e, int nact, int q2, float *Et, int Nm, int Nc)
 {
     unsigned short ks[kNbHbmMaxDc]; // k runs to Nm <= q = 256 inclusive: not a byte
@@ -50,7 +60,7 @@ __host__ __device__ inline void nb_hbm_conf(const float *pairs, const int *cn_sr
                     ks[d] = 0;
                     continue;
                 }
-                if (s > Et[sym]) Et[sym] = s; // begin > end (:322-325)
+                if (s > Et[sym >> 2]) Et[sym >> 2] = s; // begin > end (:322-325)
                 sym ^= m;                     // :342-344
                 s = s - pr.x;
                 diff -= dk;
@@ -74,10 +84,36 @@ __host__ __device__ inline void nb_hbm_conf(const float *pairs, const int *cn_sr
     }
 }
 
+// The straight-line walk of the fused kernels for one (row, edge) thread of weight W over GF(Q): pairs in the workspace (global
+// memory), max array at Ebase in LDS, already filled with -inf (EMS_L_c2v = -DBL_MAX, :277-280: the ZS form of nb_t0, which takes
+// every leaf as a maximum and so also serves the codes with a zero coefficient).
+template <int W, int Q> __device__ void nb_cn_update_hbm(const NbArgs &a, const int *src, const float *pairs, int pst, char *Ebase, int e)
+{
+    constexpr int NACT = W - 1;
+    NbCn<NACT> c;
+    c.E = Ebase;
+    c.pairs = pairs;
+#pragma unroll
+    for (int i = 0; i < NACT; i++) {
+        const int pos = i + (i >= e ? 1 : 0); // ascending positions, skipping `except` (:327-331)
+        c.pb[i] = src[pos] * pst;
+        const float2 p0 = *reinterpret_cast<const float2 *>(pairs + c.pb[i]);
+        const float2 p1 = *reinterpret_cast<const float2 *>(pairs + c.pb[i] + 2);
+        c.v0[i] = p0.x; c.m0[i] = __float_as_int(p0.y);
+        c.v1[i] = p1.x; c.m1[i] = __float_as_int(p1.y);
+    }
+    c.s = 0.0f;
+    nb_t0<0, NACT, Q, true>(c, 0); // ConstructConf(GFQ, 1) :286
+    c.s = 0.0f;
+    int Nc = a.Nc;
+    if (a.Nc == a.dcmax_cfg - 1) Nc = W - 1; // :294-297
+    nb_conf<0, NACT>(c, 0, 0, a.Nm, Nc);     // ConstructConf(EMS_Nm, EMS_Nc) :300
+}
+
 __global__ __launch_bounds__(kNbHbmThreads) void k_nb_ems_hbm(NbArgs a)
 {
     constexpr int NT = kNbHbmThreads;
-    extern __shared__ __attribute__((aligned(16))) unsigned char mulb[]; // [q][q]
+    extern __shared__ __attribute__((aligned(16))) unsigned char mulb[]; // [q][q], then the max arrays of the check threads of one pass
     __shared__ int flag;
     const int tid = threadIdx.x;
     const int N = a.N, M = a.M, q = a.q, dv = a.dv, dc = a.dc;
@@ -88,6 +124,8 @@ __global__ __launch_bounds__(kNbHbmThreads) void k_nb_ems_hbm(NbArgs a)
     float *LLRw = E + (size_t)TC * q;                     // [N][q-1]
     int *outs = reinterpret_cast<int *>(LLRw + (size_t)N * (q - 1)); // [N]
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
+    const int QP = q + 1, chunk = nb_hbm_chunk(q);
+    float *Elds = reinterpret_cast<float *>(mulb + ((q * q + 15) & ~15)); // [chunk][q + 1]
 
     __shared__ int next_frame;
     for (int frame = blockIdx.x;; frame += gridDim.x) { // a.work: frames from a counter (they differ 20x in iterations), else strided
@@ -171,21 +209,33 @@ __global__ __launch_bounds__(kNbHbmThreads) void k_nb_ems_hbm(NbArgs a)
                 const int sym = (k < q - 1) ? k + 1 : 0;
                 float2 pr;
                 pr.x = val;
-                pr.y = __int_as_float((int)mulb[sym * q + a.vn_gf[edge]]); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :336
+                pr.y = __int_as_float((int)mulb[sym * q + a.vn_gf[edge]] << 2); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :336, as a byte offset
                 *reinterpret_cast<float2 *>(pairs + (size_t)edge * q2 + 2 * rank) = pr;
             }
             __syncthreads();
             if (tid == 0) flag = 0; // read by everybody before the barrier above, written again after the next ones
-            // ---- C: check nodes (:272-313), one thread per (row, edge) -------------------------------------------------
-            for (int thr = tid; thr < TC; thr += NT) {
-                const int row = thr / dc, e = thr - row * dc, w = a.cn_w[row];
-                if (e >= w) continue;
-                float *Et = E + (size_t)thr * q;
-                for (int k = 0; k < q; k++) Et[k] = -__builtin_inff(); // EMS_L_c2v = -DBL_MAX as a float (:277-280)
-                int Nc = a.Nc;
-                if (a.Nc == a.dcmax_cfg - 1) Nc = w - 1; // :294-297
-                nb_hbm_conf(pairs, a.cn_src + row * dc, e, w - 1, q2, Et, q, 1);     // conf(q, 1)  :286
-                nb_hbm_conf(pairs, a.cn_src + row * dc, e, w - 1, q2, Et, a.Nm, Nc); // conf(Nm, Nc) :294-300
+            // ---- C: check nodes (:272-313), one thread per (row, edge), `chunk` of them per pass (max arrays in LDS) ------------
+            for (int base = 0; base < TC; base += chunk) {
+                const int thr = base + tid;
+                if (tid < chunk && thr < TC) {
+                    const int row = thr / dc, e = thr - row * dc, w = a.cn_w[row];
+                    if (e < w) {
+                        float *Et = Elds + tid * QP;
+                        for (int k = 0; k < q; k++) Et[k] = -__builtin_inff(); // EMS_L_c2v = -DBL_MAX as a float (:277-280)
+                        const int *src = a.cn_src + row * dc;
+                        if (q == 16 && w == 21) nb_cn_update_hbm<21, 16>(a, src, pairs, q2, reinterpret_cast<char *>(Et), e);
+                        else if (q == 16 && w == 20) nb_cn_update_hbm<20, 16>(a, src, pairs, q2, reinterpret_cast<char *>(Et), e); // (the Tanner code has both)
+                        else if (q == 256 && w == 12) nb_cn_update_hbm<12, 256>(a, src, pairs, q2, reinterpret_cast<char *>(Et), e);
+                        else {
+                            int Nc = a.Nc;
+                            if (a.Nc == a.dcmax_cfg - 1) Nc = w - 1; // :294-297
+                            nb_hbm_conf(pairs, src, e, w - 1, q2, Et, q, 1);     // conf(q, 1)  :286
+                            nb_hbm_conf(pairs, src, e, w - 1, q2, Et, a.Nm, Nc); // conf(Nm, Nc) :294-300
+                        }
+                        float *Eg = E + (size_t)thr * q; // what phase A of the next iteration (and the L_c2v output) reads
+                        for (int k = 0; k < q; k++) Eg[k] = Et[k];
+                    }
+                }
             }
             __syncthreads();
         }

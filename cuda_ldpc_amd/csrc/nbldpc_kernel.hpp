@@ -296,7 +296,7 @@ template <int D, int NACT, int Q, bool ZS> __device__ __forceinline__ void nb_t0
         int sfx = symbase; // symbol of a leaf that deviates here: every deeper position at k = 0
 #pragma unroll
         for (int d = D + 1; d < NACT; d++) sfx ^= c.m0[d];
-        constexpr int CH = ((Q - 1) % 7 == 0) ? 7 : 1;
+        constexpr int CH = ((Q - 1) % 7 == 0) ? 7 : ((Q - 1) % 5 == 0) ? 5 : ((Q - 1) % 3 == 0) ? 3 : 1; // 63 = 9 x 7, 255 = 51 x 5, 15 = 3 x 5
         float2 pr[CH];
 #pragma unroll
         for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (1 + i));

@@ -13,7 +13,7 @@ struct Rec {
     int sym; float s; int diff;
     void go(int begin)
     {
-        if (begin > end) { if (s > E[sym]) E[sym] = s; return; }
+        if (begin > end) { if (s > E[sym >> 2]) E[sym >> 2] = s; return; } // symbols travel premultiplied by 4 (byte offsets into the max array)
         if (begin == e) { go(begin + 1); return; }
         for (int k = 0; k < Nm; k++) {
             const float v = pairs[(size_t)src[begin] * q2 + 2 * k];
@@ -44,7 +44,7 @@ int main()
                         float v = (float)(rnd() % 2000) * 0.37f;
                         for (int k = 0; k < q; k++) { // descending values, arbitrary symbols
                             pairs[(size_t)i * q2 + 2 * k] = v;
-                            int m = (int)(rnd() % q);
+                            int m = (int)(rnd() % q) << 2;
                             memcpy(&pairs[(size_t)i * q2 + 2 * k + 1], &m, 4);
                             v -= (float)(rnd() % 1000) * 0.0131f;
                         }
