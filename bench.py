@@ -260,7 +260,7 @@ def run_nb(args, rank, world, dev, dist):
         return
     n_all = frames * world * args.steps
     alg_bytes = (4 * code.N * (code.q - 1) + 4 * code.N) * frames  # L_ch in + symbols out
-    kname = {0: "k_nb_ems<64>" if q == 64 else "k_nb_ems_wide<%d>" % q, 1: "k_nb_tmm<64, false>", 3: "k_nb_tmm<64, true>"}[method]
+    kname = {0: "k_nb_ems2<64>" if q == 64 else "k_nb_ems_wide<%d>" % q, 1: "k_nb_tmm<64, false>", 3: "k_nb_tmm<64, true>"}[method]
     mname = {0: "GF(%d) EMS" % q, 1: "GF(64) trellis min-max", 3: "GF(64) layered trellis min-max"}[method]
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     c = tot.cpu().tolist()
@@ -271,7 +271,7 @@ def run_nb(args, rank, world, dev, dist):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "myNBLDPC %s %s batch=%d codewords/GPU Eb/N0=%.1fdB" % ("BDS N576_K288" if q == 64 else name.replace(".txt", ""),
                                                                                      ("GF(%d) EMS(Nm=2,Nc=2)" % q) if method == 0 else mname, frames, snr),
-                   "kernel": "%s one frame per workgroup" % kname, "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
+                   "kernel": "%s %s" % (kname, "two frames in flight per workgroup (walking waves + sorting waves)" if kname.startswith("k_nb_ems2") else "one frame per workgroup"), "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(kname)[0], "traffic_source": pmc_traffic(kname)[1], "kernel": kname, "kernel_ms": kern_ms,
                      "onchip": pmc_onchip(kname, kern_ms),

@@ -18,3 +18,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIV
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES -d ${out}_sq3 -o run -- python bench.py "$@" --no-cpu-baseline --steps 2 --warmup 1 > ${out}_sq3.log 2>&1
 python profiles/summarize.py $tag $name ${out}_trace ${out}_fetch ${out}_write ${out}_sq,${out}_sq2,${out}_sq3 "$match"
 cp ${out}_bench.json profiles/${tag}_${name}_bench.json
+# gpurun merges back gpurun_out/ only: the summaries travel home in gpurun_out/profiles_out/ (copy them into profiles/ there)
+mkdir -p gpurun_out/profiles_out
+cp profiles/${tag}_${name}_bench.json profiles/${tag}_${name}_kernel_stats.csv profiles/${tag}_${name}_pmc.json gpurun_out/profiles_out/
+rm -rf ${out}_trace ${out}_fetch ${out}_write ${out}_sq ${out}_sq2 ${out}_sq3
