@@ -241,3 +241,48 @@ def test_lcg_quotient_shortcut_exhaustive():
         want = x.astype(np.float32) / np.float32(m)
         got = (x.astype(np.float64) * np.float64(1.0 / m)).astype(np.float32)
         assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
+def test_nb_reference_signature_shim_host_side(nbm, orc, tmp_path):
+    """The NB shim (shim/nbldpc_ref_shim.hpp) without a GPU: the classes have the layout of the reference's include/struct.h:9-71 on
+    this ABI (LP64), and the reference-signature host functions -- Get_H, GFInitial + tables, Get_CONSTELLATION, BitToSym, Modulate,
+    AWGNChannel_CPU, RandomModule, index_in_VN / index_in_CN, Statistic -- agree with the oracle on the reference's own data files.
+    Also proves that the shim and both main()-style sweeps compile and link against the library alone."""
+    import shutil
+    import subprocess
+    from cuda_ldpc_amd._lib import SO_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    libdir = os.path.dirname(SO_PATH)
+    common = [hipcc, "-O1", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim")]
+    link = ["-L", libdir, "-lcuda_ldpc_amd", "-Wl,-rpath," + libdir, "-pthread"]
+    exe = str(tmp_path / "nb_shim_host_test")
+    subprocess.check_call(common + [os.path.join(ROOT, "tests", "cpp", "nb_shim_host_test.cpp"), os.path.join(ROOT, "shim", "nbldpc_ref_shim.hip"), "-o", exe] + link)
+    for src, shim in (("nb_ref_main_style_sweep.cpp", "nbldpc_ref_shim.hip"), ("ref_main_style_sweep.cpp", "ldpc_ref_shim.hip")):
+        subprocess.check_call(common + [os.path.join(ROOT, "tests", "cpp", src), os.path.join(ROOT, "shim", shim), "-o", str(tmp_path / src[:-4])] + link)
+    nbd = os.path.join(ROOT, "data", "nb")
+    ocode = orc.NBCode(os.path.join(nbd, "BDS.576.288.GF.64.txt"), os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
+    sigma = orc.nb_sigma(3.0, ocode.rate)
+    out = subprocess.check_output([exe, "codeword_bds_gf64.txt", "%.9g" % sigma], cwd=nbd).decode().splitlines()
+    line = {ln.split()[0]: ln.split()[1:] for ln in out if ln and ln.split()[0].isupper()}
+    # include/struct.h:9-71 on LP64: CComplex {float,float}; LDPCCode 6 int + float + ... = 32; VN 2 ptr,int,4 ptr = 56; CN = 32; AWGNChannel 16;
+    # Simulation: float SNR @0, double sumTime @8, six longs @16..56, five floats @64..80 -> 88
+    assert line["LAYOUT"] == ["CComplex", "8", "LDPCCode", "32", "VN", "56", "CN", "32", "AWGNChannel", "16", "Simulation", "88"]
+    assert line["OFFSETS"][:14] == ["Simulation", "0", "8", "16", "24", "32", "40", "48", "56", "64", "68", "72", "76", "80"]
+    assert line["OFFSETS2"] == ["VN", "0", "8", "16", "24", "32", "40", "48", "CN", "0", "8", "16", "24", "LDPCCode", "0", "4", "8", "12", "16", "20", "24", "28"]
+    cw = np.loadtxt(os.path.join(nbd, "codeword_bds_gf64.txt"), dtype=np.int32)
+    g = line["GET_H"]
+    assert [int(x) for x in g[:3]] == [ocode.N, ocode.M, 64] and abs(float(g[3]) - ocode.rate) < 1e-7 and [int(x) for x in g[4:8]] == [6, 576, 2, 4]
+    mul, add, inv = nbm.GFInitial(64, os.path.join(nbd, "GF", "Arith.Table.GF.64.txt"))
+    assert [int(x) for x in line["GF"]] == [int(mul[2, 33]), int(add[5, 9]), int(inv[5]), int(mul[7, 9]), 7 ^ 9, int(inv[13])]
+    assert [float(x) for x in line["CON"]] == [1.0, 0.0, -1.0, 0.0] and line["BITTOSYM"] == ["1"]
+    seed = np.array([173, 173, 173], np.int32)
+    rx, _ = orc.nb_channel(ocode, cw, seed, sigma)
+    a = line["AWGN"]
+    assert [np.float32(a[0]), np.float32(a[1]), np.float32(a[2])] == [rx[0], rx[1], rx[-1]] and int(a[3], 16) == orc.fold_hash(rx)
+    assert [int(x) for x in a[4:7]] == seed.tolist()
+    st = line["STAT"]
+    assert [int(x) for x in st[:8]] == [0, 0, 0, 1, 4, 2, 4, 2 + 3 + 4 + 5]  # returns 1 when >= 2 error frames and >= 3 frames
+    assert abs(float(st[8]) - 0.5) < 1e-7 and abs(float(st[9]) - 4 / 4 / 96) < 1e-9 and abs(float(st[10]) - 14 / 4) < 1e-6  # "BER" = symbol errors / frames / N (sic)
+
