@@ -67,7 +67,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // (offsets, not integer-cast pointers: the stores below must stay LDS stores)
     const int o1 = (int)((((reinterpret_cast<char *>(t_elive + NE) - reinterpret_cast<char *>(lds)) + 15) & ~15) / 4);
     int *outs1 = reinterpret_cast<int *>(lds) + o1; // [N] slot 1
-    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] slot retired in this half-step; [4] pairs hold a sorted frame
+    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step)
     for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
     for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
     for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
@@ -77,7 +77,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
     if (tid == 0) {
         const int f = atomicAdd(a.work, 2); // the first two frames of this workgroup
-        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0;
+        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0;
     }
     __syncthreads();
 
@@ -92,13 +92,23 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
 #else
 #define NB_PT(i)
 #endif
+    // ONE workgroup barrier per half-step, at the end of stage 1 (everyone needs everyone there: the walk needs every wave's stores
+    // into `pairs`, the syndrome every wave's hard symbols).  The end of stage 2 is NOT a barrier: a sorting wave only has to know
+    // that the WALK of this half-step is over before it overwrites `pairs` and reads E in the next stage 1, so the walking waves
+    // count themselves off in st[5] (after their LDS operations have landed) and the sorting waves poll it.  The sorting waves of
+    // the SIMD that hosts no walking wave finish their sorts ~5 k cycles before the others and start the next stage 1 -- where
+    // that SIMD, with four of them, is the slow one -- that much earlier.
     if (is_c) {
         for (int h = 0;; h++) {
-            const int s = h & 1;
-            if (frame0 >= a.B && frame1 >= a.B) break; // the counter only grows: both slots are past the batch
+            const int s = h & 1, c = s ^ 1;
             NB_PT(0)
             __syncthreads(); // ---- end of stage 1: slot c's sorted pairs are in `pairs` (st[4]), E has been read by A(s)
             NB_PT(1)
+            if (h > 0 && __builtin_amdgcn_readfirstlane(st[2 + c]) == h) { // slot c retired in the previous half-step: its next frame
+                const int f = __builtin_amdgcn_readfirstlane(st[c]);
+                if (c) frame1 = f; else frame0 = f;
+            }
+            if (frame0 >= a.B && frame1 >= a.B) break; // the counter only grows: both slots are past the batch
             if (NB_PIPE_PRIO == 2) __builtin_amdgcn_s_setprio(3);
             if (__builtin_amdgcn_readfirstlane(st[4]) && tid < TC) { // C(c): check nodes (:272-303)
                 const int row = tid / dc, e = tid - row * dc, w = t_cn_w[row];
@@ -115,15 +125,13 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
             }
             if (NB_PIPE_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             NB_PT(2)
-            __syncthreads(); // ---- end of stage 2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's reads of `pairs` and stores into E have landed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&st[5], 1);
             NB_PT(3)
 #ifdef NB_STAMP
             nhalf++;
 #endif
-            if (__builtin_amdgcn_readfirstlane(st[2 + s])) { // slot s retired in this half-step: its next frame
-                const int f = __builtin_amdgcn_readfirstlane(st[s]);
-                if (s) frame1 = f; else frame0 = f;
-            }
         }
 #ifdef NB_STAMP
         if (tid == 0 && blockIdx.x == 0 && a.LLR) {
@@ -175,8 +183,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     const int abw_fixed = abw;
     for (int h = 0;; h++) {
         const int s = h & 1;
-        const int frame_s = s ? frame1 : frame0, frame_c = s ? frame0 : frame1;
-        if (frame_s >= a.B && frame_c >= a.B) break;
+        const int frame_s = s ? frame1 : frame0;
         const bool act_s = frame_s < a.B;
         int abw = abw_fixed; // opaque per half-step: left alone the compiler hoists every column's addresses out of the loop and spills ~150 scalars
         asm volatile("" : "+s"(abw));
@@ -198,10 +205,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                     }
                 }
             }
-            if (abw == 0 && lane == 0) {
-                st[4] = have ? 1 : 0;
-                st[2 + s] = 0; // "slot s retired": set in this half-step's S, read by every wave after the second barrier
-            }
+            if (abw == 0 && lane == 0) st[4] = have ? 1 : 0;
             if (s) sorted0 = false; else sorted1 = false;
             if (act_s) {
                 const int it = (s ? it1 : it0) + 1;
@@ -246,6 +250,12 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         NB_PT(0)
         __syncthreads();
         NB_PT(1)
+        if (h > 0 && __builtin_amdgcn_readfirstlane(st[2 + (s ^ 1)]) == h) { // slot c retired in the previous half-step: its next frame
+            const int f = __builtin_amdgcn_readfirstlane(st[s ^ 1]);
+            if (s) frame0 = f; else frame1 = f;
+        }
+        const int frame_c = s ? frame0 : frame1;
+        if (frame_s >= a.B && frame_c >= a.B) break; // the counter only grows: both slots are past the batch
         // ---- stage 2 ----------------------------------------------------------------------------------------------------
         if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(3);
         load_lch(frame_c); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
@@ -266,7 +276,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                     a.iters[frame_s] = bad ? it : it - 1;
                     a.ok[frame_s] = bad ? 0 : 1;
                     st[s] = atomicAdd(a.work, 1);
-                    st[2 + s] = 1;
+                    st[2 + s] = h + 1; // read by every wave after the next barrier; the next write is two barriers away
                 }
                 if (s) it1 = 0; else it0 = 0;
             } else {
@@ -328,14 +338,12 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         }
         if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         NB_PT(2)
-        __syncthreads();
+        // the walk of this half-step must be over before this wave touches `pairs` / E again (see the walking waves' loop)
+        while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(&st[5])) < NCW * (h + 1)) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef NB_STAMP
         nhalf++;
 #endif
-        if (__builtin_amdgcn_readfirstlane(st[2 + s])) { // slot s retired in this half-step: its next frame
-            const int f = __builtin_amdgcn_readfirstlane(st[s]);
-            if (s) frame1 = f; else frame0 = f;
-        }
     }
 #ifdef NB_STAMP
     if (abw == 0 && lane == 0 && blockIdx.x == 0 && a.LLR) {
