@@ -17,7 +17,7 @@
 //       -- barrier --
 //       stage 2   C waves: C(c): pairs -> E                      |  AB waves: S(s) (every wave for itself: no extra barrier),
 //                                                                 |            B(s): v2c(s) sorted in registers
-//       -- barrier --
+//       -- no barrier: the walking waves count themselves off in LDS, a sorting wave polls that count before its next stage 1 --
 //
 // so one `pairs` array and one `E` array serve both frames (E is free once A(s) has read it; pairs is free once C has read it)
 // and the walk's latency chains run in the shadow of the other frame's sorts.  A frame whose syndrome is zero (or that has used
