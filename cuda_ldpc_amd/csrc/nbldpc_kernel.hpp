@@ -297,23 +297,24 @@ template <int D, int NACT, int Q, bool ZS> __device__ __forceinline__ void nb_t0
 #pragma unroll
         for (int d = D + 1; d < NACT; d++) sfx ^= c.m0[d];
         constexpr int CH = ((Q - 1) % 7 == 0) ? 7 : ((Q - 1) % 5 == 0) ? 5 : ((Q - 1) % 3 == 0) ? 3 : 1; // 63 = 9 x 7, 255 = 51 x 5, 15 = 3 x 5
-        float2 pr[CH];
+        // Two register sets for the prefetched pairs, used in turn (the loop body is written out twice): with one set, read by this
+        // batch and overwritten by the prefetch of the next, the compiler copied all 2 CH registers every round (two v_mov_b32 per leaf
+        // between the links of a chain that pays 4 cycles for every independent instruction).
+        constexpr int NB = (Q - 1) / CH; // batches: 9 (q = 64), 51 (q = 256), 3 (q = 16)
+        static_assert(NB * CH == Q - 1, "whole batches");
+        float2 prA[CH], prB[CH];
 #pragma unroll
-        for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (1 + i));
-#pragma unroll 1
-        for (int k0 = 1; k0 < Q; k0 += CH) {
+        for (int i = 0; i < CH; i++) prA[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (1 + i));
+        auto batch = [&](const float2 (&cur)[CH], float2 (&nxt)[CH], int kn) { // walk the CH leaves of `cur`; meanwhile fetch batch kn into `nxt`
             float v[CH], sl[CH];
             int sy[CH];
 #pragma unroll
             for (int i = 0; i < CH; i++) {
-                v[i] = pr[i].x;
-                sy[i] = sfx ^ __float_as_int(pr[i].y); // byte offset of the leaf's symbol
+                v[i] = cur[i].x;
+                sy[i] = sfx ^ __float_as_int(cur[i].y); // byte offset of the leaf's symbol
             }
-            {   // the next batch's pairs (the last round re-reads its own: no branch in the loop)
-                const int kn = (k0 + CH < Q) ? k0 + CH : k0;
 #pragma unroll
-                for (int i = 0; i < CH; i++) pr[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (kn + i));
-            }
+            for (int i = 0; i < CH; i++) nxt[i] = *reinterpret_cast<const float2 *>(c.pairs + c.pb[D] + 2 * (kn + i));
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 int unused;
@@ -323,7 +324,13 @@ template <int D, int NACT, int Q, bool ZS> __device__ __forceinline__ void nb_t0
             }
 #pragma unroll
             for (int i = 0; i < CH; i++) nb_ds_max(c.E, sy[i], sl[i]); // :322-325
+        };
+#pragma unroll 1
+        for (int b = 0; b + 1 < NB; b += 2) {
+            batch(prA, prB, 1 + (b + 1) * CH);
+            batch(prB, prA, 1 + min(b + 2, NB - 1) * CH); // (the last pair of an even count re-reads a valid batch: no branch in the loop)
         }
+        if constexpr (NB % 2 == 1) batch(prA, prB, 1); // the odd batch out (its prefetch is a dummy)
     }
 }
 
