@@ -171,22 +171,32 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // channel vectors of the columns of this wave for the slot whose phase A comes next: loaded one half-step ahead (global
     // memory, ~1 us away), so that the loads fly during the sorts of the other slot
     float lch[CPW];
-    auto load_lch = [&](int frame) {
+    // (lane q-1 loads its neighbour's entry: every use of its lch / llr below is masked by `active`.  Scalar base per column + one
+    // constant lane offset: no vector address arithmetic; `abw` comes in as a parameter so that the column bases are recomputed on
+    // the scalar unit every half-step instead of being hoisted out of the loop and spilled)
+    unsigned lch_lo = (unsigned)min(lane, q - 2);
+    auto load_lch = [&](int frame, int abw_) {
         const float *Lch = a.Lch + (size_t)min(frame, a.B - 1) * N * (q - 1);
-        int lo = lane;
+        unsigned lo = lch_lo;
         asm volatile("" : "+v"(lo)); // opaque: the loads are issued here
 #pragma unroll
-        for (int ci = 0; ci < CPW; ci++) lch[ci] = active ? Lch[min(abw + ci * NAB, N - 1) * (q - 1) + lo] : 0.0f;
+        for (int ci = 0; ci < CPW; ci++) {
+            const float *p = Lch + min(abw_ + ci * NAB, N - 1) * (q - 1);
+            lch[ci] = p[lo];
+        }
     };
-    load_lch(frame0);
+    load_lch(frame0, abw);
 
     const int abw_fixed = abw;
+    const unsigned wmask_fixed = wmask, cmask_fixed = cmask;
     for (int h = 0;; h++) {
         const int s = h & 1;
         const int frame_s = s ? frame1 : frame0;
         const bool act_s = frame_s < a.B;
         int abw = abw_fixed; // opaque per half-step: left alone the compiler hoists every column's addresses out of the loop and spills ~150 scalars
         asm volatile("" : "+s"(abw));
+        unsigned wmask = wmask_fixed, cmask = cmask_fixed; // likewise: one scalar bit test per use instead of 24 lane masks held (and spilled) across the loop
+        asm volatile("" : "+s"(wmask), "+s"(cmask));
         int *outs = outs0 + (s ? (int)(outs1 - outs0) : 0);
         float v2c[NEW];
         NB_PT(3)
@@ -258,15 +268,34 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         if (frame_s >= a.B && frame_c >= a.B) break; // the counter only grows: both slots are past the batch
         // ---- stage 2 ----------------------------------------------------------------------------------------------------
         if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(3);
-        load_lch(frame_c); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
+        load_lch(frame_c, abw); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
         if (act_s) {
             // S: syndrome (:218-238), by every AB wave for itself (lane <-> check row, 64 rows per round): no barrier of its own
             bool bad = false;
             for (int r0 = 0; r0 < M; r0 += 64) {
                 const int r = r0 + lane;
                 int sy = 0;
-                if (r < M)
-                    for (int i = 0; i < t_cn_w[r]; i++) sy ^= mulb[outs[t_cn_vn[r * dc + i]] * q + t_cn_gf[r * dc + i]];
+                if (r < M) {
+                    // four terms per round, their look-ups side by side: 3 LDS round trips per round instead of 3 per term (every
+                    // sorting wave sits in this latency right after the barrier)
+                    const int w = t_cn_w[r];
+                    for (int i0 = 0; i0 < w; i0 += 4) {
+                        int vn[4], gf[4], hs[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int i = min(i0 + k, w - 1);
+                            vn[k] = t_cn_vn[r * dc + i];
+                            gf[k] = t_cn_gf[r * dc + i];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) hs[k] = outs[vn[k]];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int m = mulb[hs[k] * q + gf[k]];
+                            sy ^= (i0 + k < w) ? m : 0;
+                        }
+                    }
+                }
                 bad = bad || (__ballot(sy != 0) != 0ull);
             }
             const int it = s ? it1 : it0;
