@@ -34,10 +34,13 @@
 
 namespace cldpc {
 
-constexpr int kNbPipeCpw = 8; // columns per AB wave (13 AB waves x 8 >= 96 columns)
+constexpr int kNbPipeCpw = 8; // column slots per AB wave (13 AB waves x 8 >= 96 columns)
+#ifndef NB_PIPE_WALK_COLS
+#define NB_PIPE_WALK_COLS 6 // what a walking wave costs its SIMD, in columns of A/S/B work (the column map below balances the SIMDs with it)
+#endif
 
-// extra LDS behind k_nb_ems's layout: the second slot's hard symbols and the slot words
-__host__ __device__ inline size_t nb_pipe_extra_lds(int N) { return (size_t)(N + 16) * sizeof(int); }
+// extra LDS behind k_nb_ems's layout: the second slot's hard symbols, the slot words, the SIMD of every wave and the column map
+__host__ __device__ inline size_t nb_pipe_extra_lds(int N) { return (size_t)(N + 16 + 16 + 16 * kNbPipeCpw / 4) * sizeof(int); }
 
 template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs a)
 {
@@ -67,7 +70,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // (offsets, not integer-cast pointers: the stores below must stay LDS stores)
     const int o1 = (int)((((reinterpret_cast<char *>(t_elive + NE) - reinterpret_cast<char *>(lds)) + 15) & ~15) / 4);
     int *outs1 = reinterpret_cast<int *>(lds) + o1; // [N] slot 1
-    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step)
+    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step); [6] sorting waves past phase A (NAB per half-step)
     for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
     for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
     for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
@@ -75,9 +78,38 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         t_cn_src[i] = (unsigned short)a.cn_src[i]; t_cn_gf[i] = (unsigned short)a.cn_gf[i]; t_cn_vn[i] = (unsigned short)a.cn_vn[i];
     }
     for (int i = tid; i < q * q; i += NT) mulb[i] = a.mul[i];
+    int *wsimd = st + 16; // [16] the SIMD each wave runs on
+    unsigned char *colmap = reinterpret_cast<unsigned char *>(st + 32); // [nwaves][CPW] the columns of each wave (0xff: none)
     if (tid == 0) {
         const int f = atomicAdd(a.work, 2); // the first two frames of this workgroup
-        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0;
+        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0; st[6] = 0;
+    }
+    if (lane == 0) wsimd[wave] = (int)((__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) >> 4) & 3u); // HW_REG_HW_ID.SIMD_ID
+    for (int i = tid; i < nwaves * CPW; i += NT) colmap[i] = 0xff;
+    __syncthreads();
+    // Column map.  The workgroup's 16 waves sit on 4 SIMDs, 4 each; a SIMD that hosts a walking wave has 3 sorting waves, one that
+    // hosts none has 4, and the walk costs its SIMD about NB_PIPE_WALK_COLS columns' worth of issue slots per half-step.  Columns are
+    // dealt out in pairs (one group of DVM * 2 = 4 sorts): each pair goes to the SIMD with the least work so far, there to the wave
+    // with the fewest pairs (the youngest wave of a SIMD, which the issue arbiter serves last, ends up with the short hand).
+    // (one wave, lane <-> wave of the workgroup; 48 rounds of a 6-step minimum)
+    if (wave == 0) {
+        const int w = lane;
+        const bool isab = w >= NCW && w < nwaves;
+        const int sd = wsimd[min(w, nwaves - 1)];
+        int ld = 0, ng = 0; // work of this lane's SIMD (in columns), pairs of this lane's wave
+        for (int c = 0; c < NCW; c++) ld += (sd == __builtin_amdgcn_readfirstlane(wsimd[c])) ? NB_PIPE_WALK_COLS : 0;
+        for (int g = 0; 2 * g < N; g++) {
+            unsigned m = (isab && ng < CPW / 2) ? (((unsigned)ld << 16) | ((unsigned)ng << 8) | (unsigned)w) : 0xffffffffu;
+#pragma unroll
+            for (int off = 32; off; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+            const int bw = (int)(m & 0xffu), bsd = __shfl(sd, bw, 64);
+            if (w == bw) {
+                colmap[w * CPW + 2 * ng] = (unsigned char)(2 * g);
+                if (2 * g + 1 < N) colmap[w * CPW + 2 * ng + 1] = (unsigned char)(2 * g + 1);
+                ng++;
+            }
+            ld += (sd == bsd) ? 2 : 0;
+        }
     }
     __syncthreads();
 
@@ -86,7 +118,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // vice versa.
     int frame0 = __builtin_amdgcn_readfirstlane(st[0]), frame1 = __builtin_amdgcn_readfirstlane(st[1]);
 #ifdef NB_STAMP
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
     long long nhalf = 0;
 #define NB_PT(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[i] += tn - tprev; tprev = tn; }
 #else
@@ -134,10 +166,11 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
 #endif
         }
 #ifdef NB_STAMP
-        if (tid == 0 && blockIdx.x == 0 && a.LLR) {
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.LLR);
-            for (int i = 0; i < 4; i++) o[i] = tacc[i];
-            o[4] = (unsigned long long)nhalf;
+        if (lane == 0 && blockIdx.x == 0 && a.LLR) { // every wave of workgroup 0: its intervals, half-steps, HW_ID (SIMD in bits 5:4)
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.LLR) + wave * 8;
+            for (int i = 0; i < 6; i++) o[i] = tacc[i];
+            o[6] = (unsigned long long)nhalf;
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
         }
 #endif
         return;
@@ -145,13 +178,17 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
 
     const bool active = lane < q - 1;          // lanes 0..q-2 <-> field elements 1..q-1
     const int sym = active ? lane + 1 : 0;     // lane q-1 carries element 0 (value 0, :250)
-    // per AB wave: its columns abw + ci * NAB, per column and edge the LDS offset of THIS lane's entry of the check thread's max
+    // per AB wave: its columns (column map above, 4 to a word), per column and edge the LDS offset of THIS lane's entry of the check thread's max
     // array, E[thr][mul(sym, h)] (the graph does not change: one read per iteration instead of three dependent look-ups)
+    static_assert(CPW == 8, "two words of four column bytes");
+    unsigned colw0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned *>(colmap + wave * CPW));
+    unsigned colw1 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned *>(colmap + wave * CPW + 4));
+    auto colof = [](unsigned c0, unsigned c1, int ci) { return (int)(((ci < 4 ? c0 : c1) >> (8 * (ci & 3))) & 0xffu); };
     int evoff[CPW][DVM];
     unsigned wmask = 0, cmask = 0; // bit ci*DVM + d: edge d of column ci exists; bit ci: the column exists
 #pragma unroll
     for (int ci = 0; ci < CPW; ci++) {
-        const int colr = abw + ci * NAB, col = min(colr, N - 1);
+        const int colr = colof(colw0, colw1, ci), col = min(colr, N - 1);
         const int w = t_vn_w[col];
         if (colr < N) cmask |= 1u << ci;
 #pragma unroll
@@ -172,23 +209,23 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // memory, ~1 us away), so that the loads fly during the sorts of the other slot
     float lch[CPW];
     // (lane q-1 loads its neighbour's entry: every use of its lch / llr below is masked by `active`.  Scalar base per column + one
-    // constant lane offset: no vector address arithmetic; `abw` comes in as a parameter so that the column bases are recomputed on
+    // constant lane offset: no vector address arithmetic; the column words come in as parameters so that the column bases are recomputed on
     // the scalar unit every half-step instead of being hoisted out of the loop and spilled)
     unsigned lch_lo = (unsigned)min(lane, q - 2);
-    auto load_lch = [&](int frame, int abw_) {
+    auto load_lch = [&](int frame, unsigned c0, unsigned c1) {
         const float *Lch = a.Lch + (size_t)min(frame, a.B - 1) * N * (q - 1);
         unsigned lo = lch_lo;
         asm volatile("" : "+v"(lo)); // opaque: the loads are issued here
 #pragma unroll
         for (int ci = 0; ci < CPW; ci++) {
-            const float *p = Lch + min(abw_ + ci * NAB, N - 1) * (q - 1);
+            const float *p = Lch + min(colof(c0, c1, ci), N - 1) * (q - 1);
             lch[ci] = p[lo];
         }
     };
-    load_lch(frame0, abw);
+    load_lch(frame0, colw0, colw1);
 
     const int abw_fixed = abw;
-    const unsigned wmask_fixed = wmask, cmask_fixed = cmask;
+    const unsigned wmask_fixed = wmask, cmask_fixed = cmask, colw0_fixed = colw0, colw1_fixed = colw1;
     for (int h = 0;; h++) {
         const int s = h & 1;
         const int frame_s = s ? frame1 : frame0;
@@ -197,10 +234,17 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         asm volatile("" : "+s"(abw));
         unsigned wmask = wmask_fixed, cmask = cmask_fixed; // likewise: one scalar bit test per use instead of 24 lane masks held (and spilled) across the loop
         asm volatile("" : "+s"(wmask), "+s"(cmask));
+        unsigned colw0 = colw0_fixed, colw1 = colw1_fixed;
+        asm volatile("" : "+s"(colw0), "+s"(colw1));
         int *outs = outs0 + (s ? (int)(outs1 - outs0) : 0);
         float v2c[NEW];
-        NB_PT(3)
-        // ---- stage 1 ----------------------------------------------------------------------------------------------------
+        // the walk of the previous half-step must be over before this wave touches `pairs` / E again (see the walking waves' loop)
+        while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(&st[5])) < NCW * h) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        NB_PT(0)
+        // ---- stage 1a: everything that touches `pairs` and E -----------------------------------------------------------------
+        float evs[NEW]; // the max-array entries of this wave's columns (read before the barrier: the walk behind it overwrites E)
+        bool fresh = false;
         {
             const bool have = s ? sorted0 : sorted1; // slot c was sorted in the previous half-step
             if (have) {
@@ -211,7 +255,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                         float2 pr;
                         pr.x = sval[j];
                         pr.y = __int_as_float((int)((ssym[j >> 2] >> (8 * (j & 3))) & 0xffu) << 2); // byte offset into the thread's max array
-                        *reinterpret_cast<float2 *>(pairs + ((abw + ci * NAB) * dv + d) * PST + 2 * lane) = pr;
+                        *reinterpret_cast<float2 *>(pairs + (colof(colw0, colw1, ci) * dv + d) * PST + 2 * lane) = pr;
                     }
                 }
             }
@@ -220,55 +264,78 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
             if (act_s) {
                 const int it = (s ? it1 : it0) + 1;
                 if (s) it1 = it; else it0 = it;
-                const bool fresh = it == 1; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
-                float *LLRo = a.LLR ? a.LLR + (size_t)frame_s * N * (q - 1) : nullptr;
-                // all the max-array entries of this wave's columns in one batch of reads (a frame's first iteration: L_c2v = 0,
-                // made by reading nothing -- (0 - 0) / 1.2 == +0 goes through the same arithmetic, no branch)
-                float evs[NEW];
+                fresh = it == 1; // L_c2v = 0 (:185-193): (0-0)/1.2 == +0
+                // all the entries in one batch of reads (a frame's first iteration: L_c2v = 0, made by reading nothing --
+                // (0 - 0) / 1.2 == +0 goes through the same arithmetic, no branch)
 #pragma unroll
                 for (int j = 0; j < NEW; j++) evs[j] = E[evoff[j / DVM][j % DVM]];
 #pragma unroll
                 for (int j = 0; j < NEW; j++) evs[j] = fresh ? 0.0f : evs[j];
-#pragma unroll
-                for (int ci = 0; ci < CPW; ci++) {
-                    const int col = min(abw + ci * NAB, N - 1);
-                    float llr = lch[ci];
-                    float c2[DVM];
-#pragma unroll
-                    for (int d = 0; d < DVM; d++) {
-                        const float ev = evs[ci * DVM + d];
-                        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), Q - 1));
-                        const float c = nb_div12(ev - e0); // :309, double division
-                        const bool on = (wmask >> (ci * DVM + d)) & 1u;
-                        c2[d] = on ? c : 0.0f;
-                        llr = on ? llr + c : llr; // :208-213, ascending d
-                    }
-                    // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
-                    const float v = active ? llr : -__builtin_inff();
-                    const float mx = nb_wave_max(v);
-                    const unsigned long long eq = __ballot(active && v == mx);
-                    const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
-                    if ((cmask >> ci) & 1u) {
-                        if (lane == 0) outs[col] = dec;
-                        if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
-                    }
-#pragma unroll
-                    for (int d = 0; d < DVM; d++) v2c[ci * DVM + d] = active ? llr - c2[d] : 0.0f; // :241-251 (element 0: value 0)
-                }
             }
         }
-        NB_PT(0)
-        __syncthreads();
         NB_PT(1)
+        __syncthreads(); // ---- slot c's sorted pairs are in `pairs` (st[4]), E(s) has been read: the walking waves start C(c) here
+        NB_PT(2)
         if (h > 0 && __builtin_amdgcn_readfirstlane(st[2 + (s ^ 1)]) == h) { // slot c retired in the previous half-step: its next frame
             const int f = __builtin_amdgcn_readfirstlane(st[s ^ 1]);
             if (s) frame0 = f; else frame1 = f;
         }
         const int frame_c = s ? frame0 : frame1;
         if (frame_s >= a.B && frame_c >= a.B) break; // the counter only grows: both slots are past the batch
-        // ---- stage 2 ----------------------------------------------------------------------------------------------------
         if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(3);
-        load_lch(frame_c, abw); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
+        // ---- stage 1b: A(s) on the values read above, beside the walk -----------------------------------------------------------
+        if (act_s) {
+            float *LLRo = a.LLR ? a.LLR + (size_t)frame_s * N * (q - 1) : nullptr;
+#pragma unroll
+            for (int ci = 0; ci < CPW; ci++) {
+                if (!((cmask >> ci) & 1u)) { // no such column (scalar branch): its sorts are skipped as well
+#pragma unroll
+                    for (int d = 0; d < DVM; d++) v2c[ci * DVM + d] = 0.0f;
+                    continue;
+                }
+                const int col = colof(colw0, colw1, ci);
+                float llr = lch[ci];
+                float c2[DVM];
+#pragma unroll
+                for (int d = 0; d < DVM; d++) {
+                    const float ev = evs[ci * DVM + d];
+                    const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), Q - 1));
+                    c2[d] = nb_div12(ev - e0); // :309, double division
+                }
+                constexpr unsigned FULL = (1u << DVM) - 1u;
+                if (((wmask >> (ci * DVM)) & FULL) == FULL) { // every edge of the column exists (scalar branch): no selects
+#pragma unroll
+                    for (int d = 0; d < DVM; d++) llr = llr + c2[d]; // :208-213, ascending d
+                } else {
+#pragma unroll
+                    for (int d = 0; d < DVM; d++) {
+                        const bool on = (wmask >> (ci * DVM + d)) & 1u;
+                        c2[d] = on ? c2[d] : 0.0f;
+                        llr = on ? llr + c2[d] : llr;
+                    }
+                }
+                // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
+                const float v = active ? llr : -__builtin_inff();
+                const float mx = nb_wave_max(v);
+                const unsigned long long eq = __ballot(active && v == mx);
+                const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
+                if (lane == 0) outs[col] = dec;
+                if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
+#pragma unroll
+                for (int d = 0; d < DVM; d++) v2c[ci * DVM + d] = active ? llr - c2[d] : 0.0f; // :241-251 (element 0: value 0)
+            }
+        }
+        // the syndrome needs every sorting wave's hard symbols: they count themselves off in st[6] and poll (the walking waves are
+        // busy and must not be part of this: no workgroup barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) atomicAdd(&st[6], 1);
+        NB_PT(3)
+        while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(&st[6])) < NAB * (h + 1)) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        NB_PT(4)
+        // ---- stage 2 ----------------------------------------------------------------------------------------------------
+        load_lch(frame_c, colw0, colw1); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
         if (act_s) {
             // S: syndrome (:218-238), by every AB wave for itself (lane <-> check row, 64 rows per round): no barrier of its own
             bool bad = false;
@@ -312,6 +379,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 // B: stable descending sort of every v2c vector (:17-36, :253-269), as in k_nb_ems but from and to registers
 #pragma unroll
                 for (int g = 0; g < NEW / SW; g++) {
+                    if (((wmask >> (g * SW)) & ((1u << SW) - 1u)) == 0u) continue; // none of these edges exists (scalar branch)
                     uint32_t khi[SW], k32[SW];
 #pragma unroll
                     for (int i = 0; i < SW; i++) {
@@ -355,7 +423,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
 #pragma unroll
                     for (int i = 0; i < SW; i++) {
                         const int j = g * SW + i, ci = j / DVM, d = j % DVM;
-                        const int edge = min(abw + ci * NAB, N - 1) * dv + min(d, dv - 1);
+                        const int edge = min(colof(colw0, colw1, ci), N - 1) * dv + min(d, dv - 1);
                         const int symk = (idx[i] < q - 1) ? idx[i] + 1 : 0; // idx: original position of the element that belongs at position `lane`
                         sval[j] = __shfl(v2c[j], idx[i], 64);
                         pk |= (unsigned)mulb[symk * q + t_vn_gf[edge]] << (8 * i); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
@@ -366,19 +434,17 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
             }
         }
         if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        NB_PT(2)
-        // the walk of this half-step must be over before this wave touches `pairs` / E again (see the walking waves' loop)
-        while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(&st[5])) < NCW * (h + 1)) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        NB_PT(5)
 #ifdef NB_STAMP
         nhalf++;
 #endif
     }
 #ifdef NB_STAMP
-    if (abw == 0 && lane == 0 && blockIdx.x == 0 && a.LLR) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.LLR) + 8;
-        for (int i = 0; i < 4; i++) o[i] = tacc[i];
-        o[4] = (unsigned long long)nhalf;
+    if (lane == 0 && blockIdx.x == 0 && a.LLR) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.LLR) + wave * 8;
+        for (int i = 0; i < 6; i++) o[i] = tacc[i];
+        o[6] = (unsigned long long)nhalf;
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
     }
 #endif
 }
