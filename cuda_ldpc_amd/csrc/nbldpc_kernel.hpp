@@ -211,10 +211,13 @@ template <int K, int J> __device__ __forceinline__ void nb_bitonic_merge32(uint3
     nb_bitonic_step32x4<K, J>(k, kmw);
     if constexpr (J > 1) nb_bitonic_merge32<K, J / 2>(k, kmw);
 }
-template <int K> __device__ __forceinline__ void nb_bitonic_sort32(uint32_t (&k)[4], uint32_t kmw)
+// kmw_cold: the same word again for the merges up to KC -- a caller inside a loop passes an opaque copy, so that the lane masks of
+// those steps are extracted where they are used (one v_bfe_i32 each) instead of being hoisted out of the loop into registers the
+// kernel does not have (k_nb_ems2: all 21 hoisted, three of them spilled to scratch and reloaded inside every sort)
+template <int K, int KC = 0> __device__ __forceinline__ void nb_bitonic_sort32(uint32_t (&k)[4], uint32_t kmw, uint32_t kmw_cold = 0)
 {
-    if constexpr (K > 2) nb_bitonic_sort32<K / 2>(k, kmw);
-    nb_bitonic_merge32<K, K / 2>(k, kmw);
+    if constexpr (K > 2) nb_bitonic_sort32<K / 2, KC>(k, kmw, kmw_cold);
+    nb_bitonic_merge32<K, K / 2>(k, K <= KC ? kmw_cold : kmw);
 }
 
 template <int NACT> struct NbCn {

@@ -35,6 +35,9 @@
 namespace cldpc {
 
 constexpr int kNbPipeCpw = 8; // column slots per AB wave (13 AB waves x 8 >= 96 columns)
+#ifndef NB_PIPE_COLD_K
+#define NB_PIPE_COLD_K 8 // the lane masks of the merges up to this size are extracted inside the loop (see nb_bitonic_sort32)
+#endif
 #ifndef NB_PIPE_WALK_COLS
 #define NB_PIPE_WALK_COLS 6 // what a walking wave costs its SIMD, in columns of A/S/B work (the column map below balances the SIMDs with it)
 #endif
@@ -198,6 +201,19 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
             if (d < w && colr < N) wmask |= 1u << (ci * DVM + d);
         }
     }
+    // premultiplied symbols of THIS lane's field element on the wave's edges, one byte each (4 edges = one group of sorts per word)
+    static_assert(SW == 4, "one word of symbol bytes per group");
+    uint32_t pmw[NEW / SW];
+#pragma unroll
+    for (int g = 0; g < NEW / SW; g++) {
+        pmw[g] = 0;
+#pragma unroll
+        for (int i = 0; i < SW; i++) {
+            const int j = g * SW + i, ci = j / DVM, d = j % DVM;
+            const int edge = min(colof(colw0, colw1, ci), N - 1) * dv + min(d, dv - 1);
+            pmw[g] |= (uint32_t)mulb[sym * q + t_vn_gf[edge]] << (8 * i);
+        }
+    }
     wmask = __builtin_amdgcn_readfirstlane(wmask); // wave-uniform by construction; the compiler cannot know (they come out of LDS):
     cmask = __builtin_amdgcn_readfirstlane(cmask); // as scalars, the tests below are scalar branches instead of EXEC masking
     int it0 = 0, it1 = 0;
@@ -239,7 +255,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         int *outs = outs0 + (s ? (int)(outs1 - outs0) : 0);
         float v2c[NEW];
         // the walk of the previous half-step must be over before this wave touches `pairs` / E again (see the walking waves' loop)
-        while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(&st[5])) < NCW * h) __builtin_amdgcn_s_sleep(2);
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NCW * h) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         NB_PT(0)
         // ---- stage 1a: everything that touches `pairs` and E -----------------------------------------------------------------
@@ -317,7 +333,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
                 const float v = active ? llr : -__builtin_inff();
                 const float mx = nb_wave_max(v);
-                const unsigned long long eq = __ballot(active && v == mx);
+                const unsigned long long eq = __builtin_amdgcn_ballot_w64(active && v == mx);
                 const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
                 if (lane == 0) outs[col] = dec;
                 if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
@@ -331,7 +347,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) atomicAdd(&st[6], 1);
         NB_PT(3)
-        while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(&st[6])) < NAB * (h + 1)) __builtin_amdgcn_s_sleep(1);
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NAB * (h + 1)) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         NB_PT(4)
         // ---- stage 2 ----------------------------------------------------------------------------------------------------
@@ -363,7 +379,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                         }
                     }
                 }
-                bad = bad || (__ballot(sy != 0) != 0ull);
+                bad = bad || (__builtin_amdgcn_ballot_w64(sy != 0) != 0ull);
             }
             const int it = s ? it1 : it0;
             if (!bad || it == a.max_iter) { // the frame leaves: zero syndrome (:232-238, iter_number-- first) or maxIT iterations used
@@ -384,18 +400,32 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
 #pragma unroll
                     for (int i = 0; i < SW; i++) {
                         const uint32_t b = __float_as_uint(v2c[g * SW + i] + 0.0f); // +0.0f folds -0 onto +0 (they compare equal)
-                        khi[i] = (lane < q) ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;
+                        const uint32_t sg = (uint32_t)((int)b >> 31);               // order-preserving image: ~b below zero, b | sign bit above
+                        khi[i] = (b ^ sg) | (~sg & 0x80000000u);
                         k32[i] = (khi[i] & 0xffffffc0u) | (63u - (unsigned)lane);
                     }
-                    nb_bitonic_sort32<64>(k32, kmw);
+                    uint32_t kmw_cold = kmw;
+                    asm volatile("" : "+v"(kmw_cold));
+                    nb_bitonic_sort32<64, NB_PIPE_COLD_K>(k32, kmw, kmw_cold);
                     int idx[SW];
-                    bool amb = false; // two neighbours of the sorted order agree in the 26 bits the short keys carry
-#pragma unroll
-                    for (int i = 0; i < SW; i++) {
-                        idx[i] = 63 - (int)(k32[i] & 63u);
-                        const uint32_t nk = (uint32_t)__builtin_amdgcn_update_dpp((int)k32[i], (int)k32[i], 0x130, 0xf, 0xf, false); // wave_shl:1
-                        amb = amb || (__ballot(((k32[i] ^ nk) < 64u) && lane < 63) != 0ull);
+                    // two neighbours of the sorted order agree in the 26 bits the short keys carry?  key ^ next lane's key in one
+                    // instruction each (DPP operand; lane 63 has no neighbour and is masked out of the ballots)
+                    bool amb;
+                    {
+                        uint32_t x0, x1, x2, x3;
+                        asm("s_nop 1\n\t"
+                            "v_xor_b32_dpp %0, %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                            "v_xor_b32_dpp %1, %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                            "v_xor_b32_dpp %2, %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                            "v_xor_b32_dpp %3, %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                            : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(k32[0]), "v"(k32[1]), "v"(k32[2]), "v"(k32[3]));
+                        static_assert(SW == 4, "four sorts in flight");
+                        const unsigned long long am = __builtin_amdgcn_ballot_w64(x0 < 64u) | __builtin_amdgcn_ballot_w64(x1 < 64u) |
+                                                      __builtin_amdgcn_ballot_w64(x2 < 64u) | __builtin_amdgcn_ballot_w64(x3 < 64u);
+                        amb = (am & 0x7fffffffffffffffull) != 0ull;
                     }
+#pragma unroll
+                    for (int i = 0; i < SW; i++) idx[i] = (int)(~k32[i] & 63u); // the key's low bits are 63 - (original position)
                     // No such pair: all 64 short keys differ above their index bits, so their order IS the order of the full
                     // (value, index) keys.  Otherwise verify the permutation against the full keys, as k_nb_ems does.
                     if (amb) {
@@ -408,7 +438,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                             const uint32_t nimg = (uint32_t)__builtin_amdgcn_update_dpp((int)img[i], (int)img[i], 0x130, 0xf, 0xf, false);
                             const int nidx = __builtin_amdgcn_update_dpp(idx[i], idx[i], 0x130, 0xf, 0xf, false);
                             const bool in_order = img[i] > nimg || (img[i] == nimg && idx[i] < nidx);
-                            redo = redo || (__ballot(!in_order && lane < 63) != 0ull);
+                            redo = redo || (__builtin_amdgcn_ballot_w64(!in_order && lane < 63) != 0ull);
                         }
                         if (redo) { // two values that differ only in their low 6 bits: this group again, on the full keys (wave-uniform branch)
                             uint32_t klo[SW];
@@ -419,16 +449,18 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                             for (int i = 0; i < SW; i++) idx[i] = 63 - (int)klo[i];
                         }
                     }
-                    unsigned pk = 0;
+                    // idx: original position of the element that belongs at position `lane`.  Its value and its premultiplied symbol
+                    // (GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334; a constant of the original lane, pmw) come over with the same
+                    // permutation; byte i of the i-th permuted word is the i-th edge's
+                    uint32_t r[SW];
 #pragma unroll
                     for (int i = 0; i < SW; i++) {
-                        const int j = g * SW + i, ci = j / DVM, d = j % DVM;
-                        const int edge = min(colof(colw0, colw1, ci), N - 1) * dv + min(d, dv - 1);
-                        const int symk = (idx[i] < q - 1) ? idx[i] + 1 : 0; // idx: original position of the element that belongs at position `lane`
-                        sval[j] = __shfl(v2c[j], idx[i], 64);
-                        pk |= (unsigned)mulb[symk * q + t_vn_gf[edge]] << (8 * i); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334
+                        const int a4 = idx[i] << 2;
+                        sval[g * SW + i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a4, __builtin_bit_cast(int, v2c[g * SW + i])));
+                        r[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)pmw[g]);
                     }
-                    ssym[g] = pk;
+                    const uint32_t t1 = (r[0] & 0xffu) | (r[1] & ~0xffu), t2 = (t1 & 0xffffu) | (r[2] & ~0xffffu);
+                    ssym[g] = (t2 & 0xffffffu) | (r[3] & ~0xffffffu);
                 }
                 if (s) sorted1 = true; else sorted0 = true;
             }
