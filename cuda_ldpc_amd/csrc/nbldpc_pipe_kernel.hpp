@@ -36,10 +36,16 @@ namespace cldpc {
 
 constexpr int kNbPipeCpw = 8; // column slots per AB wave (13 AB waves x 8 >= 96 columns)
 #ifndef NB_PIPE_COLD_K
-#define NB_PIPE_COLD_K 8 // the lane masks of the merges up to this size are extracted inside the loop (see nb_bitonic_sort32)
+#define NB_PIPE_COLD_K 4 // the lane masks of the merges up to this size are extracted inside the loop (see nb_bitonic_sort32)
+#endif
+#ifndef NB_PIPE_ONE_S
+#define NB_PIPE_ONE_S 0 // experiment: 1 = the last sorting wave to finish phase A computes the syndrome for all, 0 = every wave for itself
+#endif
+#ifndef NB_PIPE_LATE_LCH
+#define NB_PIPE_LATE_LCH 1 // experiment: 1 = the next phase A's channel values are requested after the sorts, 0 = before
 #endif
 #ifndef NB_PIPE_WALK_COLS
-#define NB_PIPE_WALK_COLS 6 // what a walking wave costs its SIMD, in columns of A/S/B work (the column map below balances the SIMDs with it)
+#define NB_PIPE_WALK_COLS 8 // what a walking wave costs its SIMD, in columns of A/S/B work (the column map below balances the SIMDs with it)
 #endif
 
 // extra LDS behind k_nb_ems's layout: the second slot's hard symbols, the slot words, the SIMD of every wave and the column map
@@ -73,7 +79,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // (offsets, not integer-cast pointers: the stores below must stay LDS stores)
     const int o1 = (int)((((reinterpret_cast<char *>(t_elive + NE) - reinterpret_cast<char *>(lds)) + 15) & ~15) / 4);
     int *outs1 = reinterpret_cast<int *>(lds) + o1; // [N] slot 1
-    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step); [6] sorting waves past phase A (NAB per half-step)
+    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step); [6] sorting waves past phase A (NAB per half-step); [7] syndrome of this half-step's frame is non-zero; [8] half-step (+ 1) whose [7] is valid
     for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
     for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
     for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
@@ -85,7 +91,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     unsigned char *colmap = reinterpret_cast<unsigned char *>(st + 32); // [nwaves][CPW] the columns of each wave (0xff: none)
     if (tid == 0) {
         const int f = atomicAdd(a.work, 2); // the first two frames of this workgroup
-        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0; st[6] = 0;
+        st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0; st[6] = 0; st[7] = 0; st[8] = 0;
     }
     if (lane == 0) wsimd[wave] = (int)((__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) >> 4) & 3u); // HW_REG_HW_ID.SIMD_ID
     for (int i = tid; i < nwaves * CPW; i += NT) colmap[i] = 0xff;
@@ -333,7 +339,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 // DecideLLRVector (:71-91): running max from 0, strict >, first maximum wins
                 const float v = active ? llr : -__builtin_inff();
                 const float mx = nb_wave_max(v);
-                const unsigned long long eq = __builtin_amdgcn_ballot_w64(active && v == mx);
+                const unsigned long long eq = __builtin_amdgcn_ballot_w64(v == mx) & ((1ull << (Q - 1)) - 1ull); // (the active lanes, as a constant)
                 const int dec = (mx > 0.0f) ? (int)__builtin_ctzll(eq) + 1 : 0;
                 if (lane == 0) outs[col] = dec;
                 if (LLRo && active) LLRo[col * (q - 1) + lane] = llr;
@@ -341,46 +347,62 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 for (int d = 0; d < DVM; d++) v2c[ci * DVM + d] = active ? llr - c2[d] : 0.0f; // :241-251 (element 0: value 0)
             }
         }
-        // the syndrome needs every sorting wave's hard symbols: they count themselves off in st[6] and poll (the walking waves are
-        // busy and must not be part of this: no workgroup barrier)
+        // The syndrome (:218-238) needs every sorting wave's hard symbols: the waves count themselves off in st[6] (the walking waves
+        // are busy and must not be part of this: no workgroup barrier), and the LAST one to arrive -- the wave the others would be
+        // waiting for anyway -- computes it for all (lane <-> check row, 64 rows per round), publishes it in st[7] and opens st[8].
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) atomicAdd(&st[6], 1);
+        int arrived = 0;
+        bool bad_own = false;
+        if (lane == 0) arrived = atomicAdd(&st[6], 1);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
         NB_PT(3)
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NAB * (h + 1)) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        NB_PT(4)
-        // ---- stage 2 ----------------------------------------------------------------------------------------------------
-        load_lch(frame_c, colw0, colw1); // phase A of the next half-step is slot c's (if this slot retires below, its new frame is loaded there)
-        if (act_s) {
-            // S: syndrome (:218-238), by every AB wave for itself (lane <-> check row, 64 rows per round): no barrier of its own
+        if (NB_PIPE_ONE_S == 0 || arrived == NAB * (h + 1) - 1) {
+            if (NB_PIPE_ONE_S == 0) while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NAB * (h + 1)) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             bool bad = false;
-            for (int r0 = 0; r0 < M; r0 += 64) {
-                const int r = r0 + lane;
-                int sy = 0;
-                if (r < M) {
-                    // four terms per round, their look-ups side by side: 3 LDS round trips per round instead of 3 per term (every
-                    // sorting wave sits in this latency right after the barrier)
-                    const int w = t_cn_w[r];
-                    for (int i0 = 0; i0 < w; i0 += 4) {
-                        int vn[4], gf[4], hs[4];
+            if (act_s) {
+                for (int r0 = 0; r0 < M; r0 += 64) {
+                    const int r = r0 + lane;
+                    int sy = 0;
+                    if (r < M) {
+                        // four terms per round, their look-ups side by side: 3 LDS round trips per round instead of 3 per term
+                        const int w = t_cn_w[r];
+                        for (int i0 = 0; i0 < w; i0 += 4) {
+                            int vn[4], gf[4], hs[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int i = min(i0 + k, w - 1);
-                            vn[k] = t_cn_vn[r * dc + i];
-                            gf[k] = t_cn_gf[r * dc + i];
-                        }
+                            for (int k = 0; k < 4; k++) {
+                                const int i = min(i0 + k, w - 1);
+                                vn[k] = t_cn_vn[r * dc + i];
+                                gf[k] = t_cn_gf[r * dc + i];
+                            }
 #pragma unroll
-                        for (int k = 0; k < 4; k++) hs[k] = outs[vn[k]];
+                            for (int k = 0; k < 4; k++) hs[k] = outs[vn[k]];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int m = mulb[hs[k] * q + gf[k]];
-                            sy ^= (i0 + k < w) ? m : 0;
+                            for (int k = 0; k < 4; k++) {
+                                const int m = mulb[hs[k] * q + gf[k]];
+                                sy ^= (i0 + k < w) ? m : 0;
+                            }
                         }
                     }
+                    bad = bad || (__builtin_amdgcn_ballot_w64(sy != 0) != 0ull);
                 }
-                bad = bad || (__builtin_amdgcn_ballot_w64(sy != 0) != 0ull);
             }
+            if (NB_PIPE_ONE_S == 0) bad_own = bad;
+            else if (lane == 0) {
+                st[7] = bad ? 1 : 0;
+                __hip_atomic_store(&st[8], h + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (NB_PIPE_ONE_S) {
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < h + 1) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const bool bad = NB_PIPE_ONE_S ? (__builtin_amdgcn_readfirstlane(st[7]) != 0) : bad_own;
+        NB_PT(4)
+        // ---- stage 2 ----------------------------------------------------------------------------------------------------
+        if (!NB_PIPE_LATE_LCH) load_lch(frame_c, colw0, colw1); // phase A of the next half-step is slot c's
+        if (act_s) {
             const int it = s ? it1 : it0;
             if (!bad || it == a.max_iter) { // the frame leaves: zero syndrome (:232-238, iter_number-- first) or maxIT iterations used
                 for (int i = abw * 64 + lane; i < N; i += NAB * 64) a.out[(size_t)frame_s * N + i] = outs[i];
@@ -465,6 +487,9 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 if (s) sorted1 = true; else sorted0 = true;
             }
         }
+        // phase A of the next half-step is slot c's: its channel values are requested here, AFTER the sorts (8 registers the sorts
+        // need), and fly while this wave waits for the walk, stores its pairs and stands at the barrier
+        if (NB_PIPE_LATE_LCH) load_lch(frame_c, colw0, colw1);
         if (NB_PIPE_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         NB_PT(5)
 #ifdef NB_STAMP
