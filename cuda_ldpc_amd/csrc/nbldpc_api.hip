@@ -285,7 +285,7 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
         // the two-frame pipeline (nbldpc_pipe_kernel.hpp): GF(64), column weights <= 2, no zero coefficient, the columns fit its A/S/B waves
         const int ncw = (M * dc + 63) / 64;
         if (!r && !hbm && have_cu && q == 64 && dv <= 2 && !c->zero_coeff && (nb_threads(q) / 64 - ncw) * kNbPipeCpw >= N && !getenv("NBLDPC_NO_PIPE")) {
-            const size_t pl = ((lds + 15) & ~(size_t)15) + nb_pipe_extra_lds(N);
+            const size_t pl = ((lds + 15) & ~(size_t)15) + nb_pipe_extra_lds(N, M, dc);
             int occ = 0;
             if (pl <= 160 * 1024 && hipFuncSetAttribute((const void *)k_nb_ems2<64, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_nb_ems2<64, 1024>, 1024, pl) == hipSuccess && occ > 0) {

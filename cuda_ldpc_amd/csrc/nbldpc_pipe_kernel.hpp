@@ -49,7 +49,12 @@ constexpr int kNbPipeCpw = 8; // column slots per AB wave (13 AB waves x 8 >= 96
 #endif
 
 // extra LDS behind k_nb_ems's layout: the second slot's hard symbols, the slot words, the SIMD of every wave and the column map
-__host__ __device__ inline size_t nb_pipe_extra_lds(int N) { return (size_t)(N + 16 + 16 + 16 * kNbPipeCpw / 4) * sizeof(int); }
+// and the syndrome's row table (two slots x M rows x 4 or 8 words)
+__host__ __device__ inline int nb_pipe_row_words(int dc) { return dc <= 4 ? 4 : 8; }
+__host__ __device__ inline size_t nb_pipe_extra_lds(int N, int M, int dc)
+{
+    return (size_t)(((N + 3) & ~3) + 16 + 16 + 16 * kNbPipeCpw / 4 + 2 * M * nb_pipe_row_words(dc)) * sizeof(int);
+}
 
 template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs a)
 {
@@ -79,7 +84,7 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
     // (offsets, not integer-cast pointers: the stores below must stay LDS stores)
     const int o1 = (int)((((reinterpret_cast<char *>(t_elive + NE) - reinterpret_cast<char *>(lds)) + 15) & ~15) / 4);
     int *outs1 = reinterpret_cast<int *>(lds) + o1; // [N] slot 1
-    int *st = outs1 + N; // slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step); [6] sorting waves past phase A (NAB per half-step); [7] syndrome of this half-step's frame is non-zero; [8] half-step (+ 1) whose [7] is valid
+    int *st = outs1 + ((N + 3) & ~3); // (16-byte aligned) slot words: [0],[1] next frame of slot 0 / 1; [2],[3] half-step (+ 1) in which the slot last retired; [4] pairs hold a sorted frame; [5] walks finished (NCW per half-step); [6] sorting waves past phase A (NAB per half-step); [7] syndrome of this half-step's frame is non-zero; [8] half-step (+ 1) whose [7] is valid
     for (int i = tid; i < N; i += NT) t_vn_w[i] = (unsigned short)a.vn_w[i];
     for (int i = tid; i < NE; i += NT) { t_vn_thr[i] = (unsigned short)a.vn_thr[i]; t_vn_gf[i] = (unsigned short)a.vn_gf[i]; }
     for (int i = tid; i < M; i += NT) t_cn_w[i] = (unsigned short)a.cn_w[i];
@@ -93,9 +98,20 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
         const int f = atomicAdd(a.work, 2); // the first two frames of this workgroup
         st[0] = f; st[1] = f + 1; st[2] = 0; st[3] = 0; st[4] = 0; st[5] = 0; st[6] = 0; st[7] = 0; st[8] = 0;
     }
+    // the syndrome's terms, one word each: byte address of the hard symbol outs_slot[variable] | coefficient << 18; a row's terms
+    // side by side (one 16-byte read), padded with (symbol 0 of the slot, coefficient 0): a product with 0 adds nothing
+    const int RW = nb_pipe_row_words(dc);
+    unsigned *rowtab = reinterpret_cast<unsigned *>(st + 64); // [2][M][RW]
     if (lane == 0) wsimd[wave] = (int)((__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) >> 4) & 3u); // HW_REG_HW_ID.SIMD_ID
     for (int i = tid; i < nwaves * CPW; i += NT) colmap[i] = 0xff;
     __syncthreads();
+    for (int i = tid; i < 2 * M * RW; i += NT) {
+        const int slot = i / (M * RW), r = (i / RW) % M, k = i % RW;
+        const int *o = slot ? outs1 : outs0;
+        const bool on = k < t_cn_w[r];
+        const int vn = on ? t_cn_vn[r * dc + k] : 0, gf = on ? t_cn_gf[r * dc + k] : 0;
+        rowtab[i] = (unsigned)(reinterpret_cast<const char *>(o + vn) - reinterpret_cast<const char *>(lds)) | ((unsigned)gf << 18);
+    }
     // Column map.  The workgroup's 16 waves sit on 4 SIMDs, 4 each; a SIMD that hosts a walking wave has 3 sorting waves, one that
     // hosts none has 4, and the walk costs its SIMD about NB_PIPE_WALK_COLS columns' worth of issue slots per half-step.  Columns are
     // dealt out in pairs (one group of DVM * 2 = 4 sorts): each pair goes to the SIMD with the least work so far, there to the wave
@@ -347,9 +363,13 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 for (int d = 0; d < DVM; d++) v2c[ci * DVM + d] = active ? llr - c2[d] : 0.0f; // :241-251 (element 0: value 0)
             }
         }
-        // The syndrome (:218-238) needs every sorting wave's hard symbols: the waves count themselves off in st[6] (the walking waves
-        // are busy and must not be part of this: no workgroup barrier), and the LAST one to arrive -- the wave the others would be
-        // waiting for anyway -- computes it for all (lane <-> check row, 64 rows per round), publishes it in st[7] and opens st[8].
+        // The syndrome (:218-238) needs every sorting wave's hard symbols: the waves count themselves off in st[6] and poll (the
+        // walking waves are busy and must not be part of this: no workgroup barrier); then every wave computes it for itself, lane <->
+        // check row, 64 rows per round.  (NB_PIPE_ONE_S: only the LAST wave to arrive computes it, publishes it in st[7] and opens
+        // st[8] -- 12 syndromes fewer per half-step, but behind one another on the critical path: 6 % slower.)
+        // The first rows' terms are constants of the graph: requested before the wait.
+        const unsigned *rt = rowtab + s * M * RW;
+        const uint4 w4first = *reinterpret_cast<const uint4 *>(rt + min(lane, M - 1) * RW);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         int arrived = 0;
@@ -365,27 +385,16 @@ template <int Q, int NT> __global__ __launch_bounds__(NT) void k_nb_ems2(NbArgs 
                 for (int r0 = 0; r0 < M; r0 += 64) {
                     const int r = r0 + lane;
                     int sy = 0;
-                    if (r < M) {
-                        // four terms per round, their look-ups side by side: 3 LDS round trips per round instead of 3 per term
-                        const int w = t_cn_w[r];
-                        for (int i0 = 0; i0 < w; i0 += 4) {
-                            int vn[4], gf[4], hs[4];
+                    for (int k0 = 0; k0 < RW; k0 += 4) { // (one round for rows of weight <= 4; two LDS round trips per round)
+                        const uint4 w4 = (r0 == 0 && k0 == 0) ? w4first : *reinterpret_cast<const uint4 *>(rt + min(r, M - 1) * RW + k0);
+                        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+                        int hs[4];
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const int i = min(i0 + k, w - 1);
-                                vn[k] = t_cn_vn[r * dc + i];
-                                gf[k] = t_cn_gf[r * dc + i];
-                            }
+                        for (int k = 0; k < 4; k++) hs[k] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lds) + (w[k] & 0x3ffffu));
 #pragma unroll
-                            for (int k = 0; k < 4; k++) hs[k] = outs[vn[k]];
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const int m = mulb[hs[k] * q + gf[k]];
-                                sy ^= (i0 + k < w) ? m : 0;
-                            }
-                        }
+                        for (int k = 0; k < 4; k++) sy ^= mulb[hs[k] * q + (int)(w[k] >> 18)];
                     }
-                    bad = bad || (__builtin_amdgcn_ballot_w64(sy != 0) != 0ull);
+                    bad = bad || (__builtin_amdgcn_ballot_w64(sy != 0 && r < M) != 0ull);
                 }
             }
             if (NB_PIPE_ONE_S == 0) bad_own = bad;
