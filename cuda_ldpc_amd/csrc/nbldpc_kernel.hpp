@@ -561,6 +561,12 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
         for (int e0 = wave * SW; e0 < NE; e0 += nwaves * SW) {
             uint32_t khi[SW], k32[SW];
             bool live[SW];
+            // premultiplied symbol of THIS lane's field element on the four edges, one byte each: a constant of the original lane, so
+            // after the sort it comes over with the permutation (one ds_bpermute) instead of through t_vn_gf -> mulb behind the network
+            static_assert(SW == 4, "one word of symbol bytes per group");
+            uint32_t pmw = 0;
+#pragma unroll
+            for (int i = 0; i < SW; i++) pmw |= (uint32_t)mulb[(active ? lane + 1 : 0) * q + t_vn_gf[min(e0 + i, NE - 1)]] << (8 * i);
 #pragma unroll
             for (int i = 0; i < SW; i++) {
                 const int edge = e0 + i;
@@ -575,20 +581,36 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
             if (!(NB_ABLATE & 2)) nb_bitonic_sort32<64>(k32, kmw);
             // verify: position `lane` holds element idx; its successor must be smaller in (image, 63 - index)
             int idx[SW];
-            uint32_t img[SW];
             bool redo = false;
 #pragma unroll
-            for (int i = 0; i < SW; i++) {
-                idx[i] = 63 - (int)(k32[i] & 63u);
-                img[i] = (uint32_t)__shfl((int)khi[i], idx[i], 64); // full image of the element now at this position
+            for (int i = 0; i < SW; i++) idx[i] = (int)(~k32[i] & 63u); // the key's low bits are 63 - (original position)
+            // two neighbours of the sorted order agree in the 26 bits the short keys carry?  (key ^ next lane's key in one instruction
+            // each; lane 63 has no neighbour.)  If none do, the short-key order IS the order of the full (value, index) keys.
+            bool amb;
+            {
+                uint32_t x0, x1, x2, x3;
+                asm("s_nop 1\n\t"
+                    "v_xor_b32_dpp %0, %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_xor_b32_dpp %1, %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_xor_b32_dpp %2, %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_xor_b32_dpp %3, %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                    : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(k32[0]), "v"(k32[1]), "v"(k32[2]), "v"(k32[3]));
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(x0 < 64u) | __builtin_amdgcn_ballot_w64(x1 < 64u) |
+                                              __builtin_amdgcn_ballot_w64(x2 < 64u) | __builtin_amdgcn_ballot_w64(x3 < 64u);
+                amb = (am & 0x7fffffffffffffffull) != 0ull;
             }
+            if (amb) { // verify against the full keys
+                uint32_t img[SW];
 #pragma unroll
-            for (int i = 0; i < SW; i++) {
-                // the successor's (image, index): DPP wave_shl:1 (lane i reads lane i + 1; lane 63 is not looked at)
-                const uint32_t nimg = (uint32_t)__builtin_amdgcn_update_dpp((int)img[i], (int)img[i], 0x130, 0xf, 0xf, false);
-                const int nidx = __builtin_amdgcn_update_dpp(idx[i], idx[i], 0x130, 0xf, 0xf, false);
-                const bool in_order = img[i] > nimg || (img[i] == nimg && idx[i] < nidx);
-                redo = redo || (__ballot(!in_order && lane < 63) != 0ull);
+                for (int i = 0; i < SW; i++) img[i] = (uint32_t)__shfl((int)khi[i], idx[i], 64); // full image of the element now at this position
+#pragma unroll
+                for (int i = 0; i < SW; i++) {
+                    // the successor's (image, index): DPP wave_shl:1 (lane i reads lane i + 1; lane 63 is not looked at)
+                    const uint32_t nimg = (uint32_t)__builtin_amdgcn_update_dpp((int)img[i], (int)img[i], 0x130, 0xf, 0xf, false);
+                    const int nidx = __builtin_amdgcn_update_dpp(idx[i], idx[i], 0x130, 0xf, 0xf, false);
+                    const bool in_order = img[i] > nimg || (img[i] == nimg && idx[i] < nidx);
+                    redo = redo || (__builtin_amdgcn_ballot_w64(!in_order && lane < 63) != 0ull);
+                }
             }
             if (redo) { // two values that differ only in their low 6 bits: this group again, on the full keys (wave-uniform branch)
                 uint32_t klo[SW];
@@ -601,11 +623,13 @@ template <int Q, int DVM, int NT> __global__ __launch_bounds__(NT) void k_nb_ems
 #pragma unroll
             for (int i = 0; i < SW; i++) {
                 const int edge = e0 + i;
+                // idx: original position of the element that belongs at position `lane`; its premultiplied symbol
+                // (GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334) is byte i of that lane's pmw
+                const uint32_t pmo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx[i] << 2, (int)pmw);
                 if (live[i] && lane < q) {
-                    const int symk = (idx[i] < q - 1) ? idx[i] + 1 : 0; // idx: original position of the element that belongs at position `lane`
                     float2 pr;
                     pr.x = pairs[edge * PST + 2 * idx[i]];
-                    pr.y = __int_as_float((int)mulb[symk * q + t_vn_gf[edge]] << 2); // GFMultiply(sort_Entr_v2c, linkVNs_GF) of :334, as a byte offset
+                    pr.y = __int_as_float((int)((pmo >> (8 * i)) & 0xffu) << 2); // as a byte offset into the thread's max array
                     *reinterpret_cast<float2 *>(pairs + edge * PST + 2 * lane) = pr;
                 }
             }
