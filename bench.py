@@ -274,7 +274,8 @@ def run_nb(args, rank, world, dev, dist):
                    "kernel": "%s %s" % (kname, "two frames in flight per workgroup (walking waves + sorting waves)" if kname.startswith("k_nb_ems2") else "one frame per workgroup"), "frames_per_gpu": frames, "sharding": "frames, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(kname)[0], "traffic_source": pmc_traffic(kname)[1], "kernel": kname, "kernel_ms": kern_ms,
-                     "onchip": pmc_onchip(kname, kern_ms),
+                     # (a frame occupies one half of a workgroup's pipeline for mean_iterations + P(converged) half-steps)
+                     "onchip": pmc_onchip(kname, kern_ms, frames=frames, iters=c[2] / n_all + 1.0 - c[0] / n_all),
                      "algorithmic_bytes_per_launch": alg_bytes},
         "stats": {"frames": n_all, "error_frames": c[0], "symbol_errors": c[1], "FER": c[0] / n_all, "SER": c[1] / n_all / code.N,
                   "mean_iterations": c[2] / n_all},
