@@ -11,16 +11,17 @@
 // ("AB waves") do phases A, S, B -- and two frame slots that run half an iteration apart:
 //
 //     half-step h (slot s = h & 1 in its A/S/B half, slot c = 1 - s in its C half)
-//       stage 1   AB waves: store slot c's sorted pairs, kept in REGISTERS since its phase B, into the one `pairs` array
-//                 (slot s's pairs, which its walk read in the previous half-step, are dead); then A(s): c2v from the one set of
-//                 max arrays E (written by C(s) in the previous half-step), LLR, hard decision, v2c(s) -> registers
-//       -- barrier --
-//       stage 2   C waves: C(c): pairs -> E                      |  AB waves: S(s) (every wave for itself: no extra barrier),
-//                                                                 |            B(s): v2c(s) sorted in registers
-//       -- no barrier: the walking waves count themselves off in LDS, a sorting wave polls that count before its next stage 1 --
+//       stage 1a  AB waves: wait for the count of finished walks; store slot c's sorted pairs, kept in REGISTERS since its phase
+//                 B, into the one `pairs` array (slot s's pairs, which its walk read in the previous half-step, are dead); read the
+//                 max-array entries E of this lane's edges of slot s (written by C(s) in the previous half-step)
+//       -- barrier (the only one) --
+//       stage 1b  C waves: C(c): pairs -> E, then count off   |  AB waves: A(s) on the values read: c2v, LLR, hard decision,
+//       stage 2                                                |  v2c(s) -> registers; count off and poll until all AB waves are
+//                                                              |  there; S(s) (every wave for itself); B(s): v2c(s) sorted in
+//                                                              |  registers; request the next half-step's channel values
 //
 // so one `pairs` array and one `E` array serve both frames (E is free once A(s) has read it; pairs is free once C has read it)
-// and the walk's latency chains run in the shadow of the other frame's sorts.  A frame whose syndrome is zero (or that has used
+// and the walk's latency chains run beside the other frame's phase A and sorts.  A frame whose syndrome is zero (or that has used
 // max_iter iterations) leaves in its S; its slot takes the next frame from the counter.  The channel vectors are re-read from
 // global memory every iteration (24 KB per frame, L2-resident) instead of living in registers: the registers hold v2c / the
 // sorted pairs.  Not offered here (k_nb_ems takes those calls): codes with a zero coefficient, column weights above 2, the
