@@ -34,6 +34,7 @@ struct nbldpc_code {
     int levels = 0;
     bool tmm_ok = false;
     int zero_coeff = 0; // an edge with coefficient 0 exists (EMS only, see nbldpc_code_create)
+    const char *last_kernel = "none"; // nbldpc_last_kernel
     int persist_grid = 0; // k_nb_ems / k_nb_ems_wide: workgroups that fill the chip once (CUs x workgroups per CU)
     bool hbm = false;   // decoded by k_nb_ems_hbm (state in a global-memory workspace): LDS too small or rows heavier than kNbMaxW
     int pipe_grid = 0;        // k_nb_ems2 (two frames in flight per workgroup): resident workgroups, 0 = kernel not offered for this code
@@ -313,6 +314,8 @@ extern "C" int nbldpc_code_create(int N, int M, int q, int dv, int dc, const int
     return NBLDPC_OK;
 }
 
+extern "C" const char *nbldpc_last_kernel(const nbldpc_code *c) { return c ? c->last_kernel : "none"; }
+
 extern "C" int nbldpc_code_destroy(nbldpc_code *c)
 {
     if (!c) return NBLDPC_OK;
@@ -348,6 +351,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         a.ws_stride = slot;
         a.work = next_work_slot(c);
         CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
+        c->last_kernel = "k_nb_ems_hbm";
         hipLaunchKernelGGL(k_nb_ems_hbm, dim3(slots), dim3(kNbHbmThreads), nb_hbm_lds_bytes(c->q), st, a);
         const hipError_t le = hipGetLastError();
         CLDPC_HIP(hipFreeAsync(ws, st), NBLDPC_EHIP);
@@ -358,6 +362,7 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         // two frames in flight per workgroup, frames from a counter (k_nb_ems2); L_c2v is not offered there
         a.work = next_work_slot(c);
         CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
+        c->last_kernel = "k_nb_ems2";
         hipLaunchKernelGGL((k_nb_ems2<64, 1024>), dim3(std::min(c->pipe_grid, (B + 1) / 2)), dim3(1024), c->pipe_lds, st, a);
         CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
         return NBLDPC_OK;
@@ -366,10 +371,12 @@ extern "C" int nbldpc_ems_decode_batch(nbldpc_code *c, const float *Lch, int B, 
         // persistent workgroups and a frame counter (k_nb_ems), zeroed stream-ordered; one ring slot per call in flight
         a.work = next_work_slot(c);
         CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
+        c->last_kernel = c->q > 64 ? "k_nb_ems_wide (frames from a counter)" : "k_nb_ems (frames from a counter)";
         hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(c->persist_grid), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
         CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
         return NBLDPC_OK;
     }
+    c->last_kernel = c->q > 64 ? "k_nb_ems_wide" : "k_nb_ems";
     hipLaunchKernelGGL(nb_kernel(c->q, c->dv), dim3(B), dim3(nb_threads(c->q)), c->lds_bytes, st, a);
     CLDPC_HIP(hipGetLastError(), NBLDPC_EHIP);
     return NBLDPC_OK;
@@ -390,7 +397,9 @@ extern "C" int nbldpc_tmm_decode_batch(nbldpc_code *c, const float *Lch, int B, 
     TmmKernel k = tmm_kernel(c->q, layered != 0);
     hipStream_t st = (hipStream_t)stream;
     const int pgrid = c->tmm_grid[layered != 0];
+    c->last_kernel = layered ? "k_nb_tmm (layered)" : "k_nb_tmm";
     if (pgrid > 0 && B > pgrid && !c->no_persist) { // persistent workgroups and a frame counter, as in nbldpc_ems_decode_batch
+        c->last_kernel = layered ? "k_nb_tmm (layered, frames from a counter)" : "k_nb_tmm (frames from a counter)";
         a.work = next_work_slot(c);
         CLDPC_HIP(hipMemsetAsync(a.work, 0, sizeof(int), st), NBLDPC_EHIP);
         hipLaunchKernelGGL(k, dim3(pgrid), dim3(kTmmThreads), lds, st, a);

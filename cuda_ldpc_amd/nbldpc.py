@@ -26,6 +26,8 @@ lib.nbldpc_statistic.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_
 lib.nbldpc_awgn_channel_host.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]
 lib.nbldpc_awgn_channel_device.argtypes = [c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
 lib.nbldpc_read_constellation.argtypes = [c_char_p, c_int, c_void_p]
+lib.nbldpc_last_kernel.argtypes = [c_void_p]
+lib.nbldpc_last_kernel.restype = ctypes.c_char_p
 lib.nbldpc_awgn_channel_host_qam.argtypes = [c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]
 lib.nbldpc_awgn_channel_device_qam.argtypes = [c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
 lib.nbldpc_demodulate_qam.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]
@@ -83,6 +85,11 @@ class NBCode:
                                       _np(self.vn_linkCNs_GF), _np(self.cn_weight), _np(self.cn_linkVNs), _np(self.cn_linkVNs_GF),
                                       _np(self.TableMultiply), ctypes.byref(h)), "nbldpc_code_create")
         self._h = h
+
+    @property
+    def last_kernel(self):
+        """Name of the kernel the last decode call on this code launched (nbldpc_last_kernel)."""
+        return lib.nbldpc_last_kernel(self._h).decode()
 
     def close(self):
         if getattr(self, "_h", None):

@@ -62,6 +62,12 @@ int nbldpc_code_create(int N, int M, int q, int dvmax, int dcmax, const int *vn_
                        const unsigned *TableMultiply, nbldpc_code **code);
 int nbldpc_code_destroy(nbldpc_code *code);
 
+/* Name of the kernel the last decode call on this code launched (static string): "k_nb_ems2" = two frames in flight per workgroup,
+ * "k_nb_ems" / "k_nb_ems_wide" one frame per workgroup (+ " (frames from a counter)": persistent workgroups), "k_nb_ems_hbm" the
+ * workspace kernel, "k_nb_tmm…" the trellis decoders.  The counterpart of bldpc_last_kernel (include/bldpc.h); the reference has no
+ * equivalent -- its kernels are fixed at compile time (myNBLDPC/src/Decode_GPU.cu:138-356). */
+const char *nbldpc_last_kernel(const nbldpc_code *code);
+
 /* Replaces Decoding_EMS / Decoding_EMS_GPU for a batch (all pointers DEVICE memory).
  *   EMS_Nm, EMS_Nc   reference macros EMS_NM / EMS_NC (define.h:31-32)
  *   maxIT            reference macro maxIT (define.h:35)

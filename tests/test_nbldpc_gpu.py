@@ -860,3 +860,74 @@ def test_pipeline_kernel_equals_the_one_frame_kernel(nb, code, monkeypatch, B, s
     for k in ("DecodeOutput", "iter_number", "ok"):
         assert torch.equal(a[k], c[k]), k
 
+
+def _irregular_gf64_code(tmp_path, nb, N, dc, drop, seed):
+    """A random GF(64) code with column weights 1 / 2 and row weights dc - 1 / dc: a (2, dc)-regular graph with `drop` edges taken
+    out (no column left without an edge, every row keeps at least two), in the reference's matrix format."""
+    rng = np.random.default_rng(seed)
+    M = N * 2 // dc
+    while True:
+        stubs = np.repeat(np.arange(N), 2)
+        rng.shuffle(stubs)
+        rows = stubs.reshape(M, dc)
+        if all(len(set(r)) == dc for r in rows):
+            break
+    gf = rng.integers(1, 64, size=(M, dc))
+    edges = [(r, int(rows[r, t]), int(gf[r, t])) for r in range(M) for t in range(dc)]
+    colw = np.full(N, 2)
+    roww = np.full(M, dc)
+    for k in rng.permutation(len(edges)):
+        if drop == 0:
+            break
+        r, c, _ = edges[k]
+        if colw[c] == 2 and roww[r] == dc:  # at most one edge out of any row or column
+            colw[c] -= 1
+            roww[r] -= 1
+            edges[k] = None
+            drop -= 1
+    edges = [e for e in edges if e is not None]
+    mpath = str(tmp_path / ("irr_%d_%d.txt" % (N, dc)))
+    with open(mpath, "w") as f:
+        f.write("%d %d 64\n2 %d\n" % (N, M, dc))
+        f.write(" ".join(str(int(w)) for w in colw) + "\n" + " ".join(str(int(w)) for w in roww) + "\n")
+        for c in range(N):
+            f.write(" ".join("%d %d" % (r + 1, h) for r, cc, h in edges if cc == c) + "\n")
+        for r in range(M):
+            f.write(" ".join("%d %d" % (c + 1, h) for rr, c, h in edges if rr == r) + "\n")
+    return mpath
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,dc,drop", [(63, 3, 0), (60, 5, 7), (90, 6, 11), (92, 4, 9)])
+def test_pipeline_kernel_on_other_gf64_graphs(nb, orc, tmp_path, monkeypatch, N, dc, drop):
+    """k_nb_ems2 is offered to every GF(64) code with column weights <= 2 whose columns fit its sorting waves, not only to the
+    reference's BDS code: an odd number of columns (half a group of sorts), rows of weight 5 and 6 (two syndrome table reads per
+    row, two or three walking waves), columns of weight 1 and rows one short (absent edges inside a group).  Against k_nb_ems on the
+    whole batch and against the oracle on its first frames."""
+    gpath = os.path.join(NB, "GF", "Arith.Table.GF.64.txt")
+    mpath = _irregular_gf64_code(tmp_path, nb, N, dc, drop, seed=N + dc)
+    mul, _, _ = nb.GFInitial(64, gpath)
+    code = nb.NBCode(mpath, mul)
+    monkeypatch.setenv("NBLDPC_NO_PIPE", "1")
+    plain = nb.NBCode(mpath, mul)
+    monkeypatch.delenv("NBLDPC_NO_PIPE")
+    ocode = orc.NBCode(mpath, gpath)
+    rng = np.random.default_rng(N * dc)
+    B = 37
+    Lch = (rng.standard_normal((B, N, 63)) * 3.0).astype(np.float32)
+    Lch[1] = np.round(Lch[1])  # ties
+    Lch[2:12] += 6.0 * (rng.random((10, N, 63)) < 0.02)  # a few strong symbols: frames that converge at different iterations
+    Lt = torch.from_numpy(Lch).cuda()
+    a = nb.Decoding_EMS(code, Lt, 2, 2, 6, want_state="llr")
+    assert code.last_kernel == "k_nb_ems2"
+    b = nb.Decoding_EMS(plain, Lt, 2, 2, 6, want_state="llr")
+    assert plain.last_kernel == "k_nb_ems"
+    torch.cuda.synchronize()
+    for k in ("DecodeOutput", "iter_number", "ok"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["LLR"].view(torch.int32), b["LLR"].view(torch.int32))
+    for f in range(3):
+        want = orc.nb_ems_decode(ocode, Lch[f], 2, 2, 6, want_state=True)
+        assert int(a["iter_number"][f]) == want["it"] and int(a["ok"][f]) == want["ok"]
+        assert np.array_equal(a["DecodeOutput"][f].cpu().numpy(), want["out"])
+        assert np.array_equal(a["LLR"][f].cpu().numpy().view(np.uint32), want["LLR"].view(np.uint32))
