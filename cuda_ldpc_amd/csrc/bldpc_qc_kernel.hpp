@@ -172,8 +172,18 @@ template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f)
 // the same LDS footprint -- on gfx950 one wave issues at most one VALU instruction per 4 cycles, a SIMD one
 // per 2, so the fused kernel needs >= 4-6 resident waves per SIMD to keep the VALU and the LDS pipe busy
 // through barriers.  The halves' (min1, min2, sign) meet through three v_permlane32_swap per frame.
-template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int GJ_, int MINW_> struct QcGeom2 {
+//
+// LOC ("local edges", round 3): a block column may be stored rotated -- which lane holds which variable of a column is free as long
+// as everybody addresses S the same way -- so for ONE of its blocks the variable (l, (t+s) mod Z) can live in the very thread that
+// owns check (j, t).  With every column handed to a half-row that contains it (CPT columns per half-row, a matching found on the
+// host) that edge never touches LDS: its R stays in the check thread's register for the variable-node sum, its S in the same
+// thread's register for the next check-node phase -- 3 of a thread's 12 R reads, 3 of its 10 S reads and 3 of its 10 R stores
+// per iteration at J4_L24_Z96.  The variable-node sum keeps the reference's order (ascending block row): with WV == J a column's
+// slot k is block row k (absent rows read the +0.0f slot: adding +0.0f to a sum that is never -0.0f is exact), the local edge of a
+// thread of block row j is slot j, and j is wave-uniform: a scalar switch picks one of J bodies.
+template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int GJ_, int MINW_, bool LOC_ = false> struct QcGeom2 {
     static constexpr int NF = NF_, J = J_, L = L_, Z = Z_, WC = WC_, WV = WV_, GJ = GJ_, MINW = MINW_;
+    static constexpr bool LOC = LOC_;
     static constexpr int ZB = Z / 32, WCH = WC / 2, NCG = 2 * GJ;
     static constexpr int RPT = J / GJ, CPT = L / NCG, TPB = GJ * ZB * 64;
     static constexpr int MSG = NF * 4;
@@ -186,6 +196,7 @@ template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int GJ_, int MINW_>
     static_assert(Z % 32 == 0 && WC % 2 == 0, "half-waves own 32 circulant positions and half a row each");
     static_assert(J % GJ == 0 && L % NCG == 0, "groups must tile the block rows and columns");
     static_assert(TPB <= 1024 && inf_slot < 65536, "geometry out of range");
+    static_assert(!LOC || (GJ == J && WV == J && L / NCG <= WC / 2 && J <= 4), "local edges: one block row per wave, a column's slot k is block row k");
 };
 
 // v_permlane32_swap a, b: a <- [a.lo, b.lo], b <- [a.hi, b.hi] (lo = lanes 0-31, hi = lanes 32-63).
@@ -516,8 +527,8 @@ __global__ __launch_bounds__(256) void k_iters_max(const int *iters, int F, int 
 
 // ---------------------------------------------------------------------------------------------
 using QcKernel = void (*)(QcArgs);
-struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; int U, CPT, regstate; QcKernel fn_pf = nullptr; };
-// fn_pf: persistent kernel for the per-frame exit (k_qc2p), or null
+struct QcVariant { int NF, J, L, Z, WC, WV, G, MINW, threads, lds_bytes; QcKernel fn, fn_hist; const char *tag; int U, CPT, regstate; QcKernel fn_pf = nullptr; int loc = 0; };
+// fn_pf: persistent kernel for the per-frame exit (k_qc2p), or null; loc: half-row kernel with local edges (QcGeom2<..., true>)
 // tag "compressed" (U != 0): J = L = 0 (any), WC = row slots, lds_bytes computed per code; tag "regstate": L = 0 (any)
 
 // Ahead-of-time variants: one per block-matrix geometry of the reference's matrix set whose message
@@ -542,6 +553,11 @@ inline const QcVariant *qc_variants(int *count)
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::TPB,                            \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, false>, \
      k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow", 0, 0, 0, k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>},
+#define X2L(NF, J, L, Z, WC, WV, GJ, MINW)                                                                      \
+    {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::TPB,                              \
+     QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, false>, \
+     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, "halfrow-local", 0, 0, 0,                            \
+     k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, 1},
 #define XC(Z, U, G, CPT, WCS)                                                                              \
     {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
      k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, true, true>},
@@ -552,6 +568,7 @@ inline const QcVariant *qc_variants(int *count)
     {1, J, L, Z, WCS, 31, 0, 2, TPB, 0, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, false>,                    \
      k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true>, "regstate-halo", 0, NG, 2, k_qcr2<Qcr2Geom<J, L, Z, TPB, WCS, YB, NG>, true, true>},
     static const QcVariant v[] = {
+        X2L(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2) with local edges: taken when every row is full and the matching exists */
         X2(2, 4, 24, 96, 20, 4, 4, 6) /* J4_L24_Z96 (BASELINE config 2): 768 thr, 80 KB, 2 WG/CU, 6 waves/SIMD */
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
         X2(2, 12, 24, 96, 8, 6, 4, 3) /* J12_L24_Z96 (rows padded 7 -> 8): 768 thr, 92 KB                        */
@@ -583,6 +600,7 @@ inline const QcVariant *qc_variants(int *count)
     };
 #undef X
 #undef X2
+#undef X2L
 #undef XC
 #undef XR
 #undef XR2
@@ -612,6 +630,7 @@ struct QcPlan {
     // experiment / test switches, read ONCE when the plan is built (never per decode call):
     bool no_persist = false;    // BLDPC_NO_PERSIST: one workgroup per frame group even where the persistent form exists
     bool force_regroup = false; // BLDPC_REGROUP: k_regroup_y in front of the row / half-row kernels instead of reading in place
+                                // (BLDPC_NO_LOCAL, also read there: the half-row kernel without local edges)
 };
 
 // bldpc_decode_statistic: per-frame error counts wanted from the pass that unpacks the hard bits (single-launch modes only).
@@ -633,6 +652,37 @@ inline void qc_plan_release(QcPlan *q)
     q->d_cn_meta = nullptr; q->d_vn_meta = nullptr;
     q->d_cn = nullptr; q->d_rowptr = nullptr; q->d_vn = nullptr; q->d_wv = nullptr;
     q->frames_per_wg = 0;
+}
+
+// Local edges of the half-row kernel (QcGeom2 LOC): hand every block column to ONE block row that contains it, 2*CPT columns per
+// row (CPT per half-row).  A bipartite matching with row capacities, by augmenting paths (J, L are tens).  owner[l] = row or -1.
+inline bool qc2_local_assign(int J, int L, const std::vector<unsigned short> &rowptr, const std::vector<QcCnEdge> &cn, std::vector<int> &owner)
+{
+    if (J <= 0 || L % (2 * J) != 0) return false;
+    const int cap = L / J;
+    std::vector<std::vector<int>> rows_of(L);
+    for (int j = 0; j < J; j++)
+        for (int e = rowptr[j]; e < rowptr[j + 1]; e++) rows_of[cn[e].col].push_back(j);
+    owner.assign(L, -1);
+    std::vector<int> cnt(J, 0), seen(J, 0);
+    struct Rec {
+        static bool place(int l, const std::vector<std::vector<int>> &rows_of, std::vector<int> &owner, std::vector<int> &cnt, std::vector<int> &seen, int cap)
+        {
+            for (int j : rows_of[l]) {
+                if (seen[j]) continue;
+                seen[j] = 1;
+                if (cnt[j] < cap) { owner[l] = j; cnt[j]++; return true; }
+                for (size_t l2 = 0; l2 < owner.size(); l2++)
+                    if (owner[l2] == j && place((int)l2, rows_of, owner, cnt, seen, cap)) { owner[l] = j; return true; } // l2 moved on (its new row counted it), l takes its place
+            }
+            return false;
+        }
+    };
+    for (int l = 0; l < L; l++) {
+        std::fill(seen.begin(), seen.end(), 0);
+        if (!Rec::place(l, rows_of, owner, cnt, seen, cap)) return false;
+    }
+    return true;
 }
 
 // Pick the first variant whose geometry matches the code, upload its block lists.  Leaves
@@ -665,6 +715,8 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     const bool no_halo = getenv("BLDPC_NO_HALO") != nullptr; // tests: k_qcr on a code k_qcr2 takes
     q->no_persist = getenv("BLDPC_NO_PERSIST") != nullptr;
     q->force_regroup = getenv("BLDPC_REGROUP") != nullptr;
+    const bool no_local = getenv("BLDPC_NO_LOCAL") != nullptr;
+    std::vector<int> owner; // half-row kernel with local edges: the block row every column is handed to
     // k_qcr2 gives per-lane addresses to two slots per (block row, tile): no more than two of a row's blocks may wrap past Z in
     // the same tile of 64 circulant positions (shifts taken relative to the register-resident column, as the kernel sees them)
     auto qcr2_fits = [&](int ng) -> bool {
@@ -700,6 +752,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         } else {
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.WV < Wv) continue;
             if ((size_t)v.lds_bytes > kLdsBytes) continue;
+            if (v.loc && (no_local || Wcmin != v.WC || !qc2_local_assign(J, L, rowptr, cn, owner))) continue; // every row full, every column placed
             q->lds_bytes = v.lds_bytes;
         }
         q->variant = vi;
@@ -814,14 +867,37 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         cn = cn2;
         rowptr = rowptr2;
     }
-    std::vector<QcVnEdge> vn((size_t)L * vnw, QcVnEdge{0, 0});
+    std::vector<int> virt_col(L);
+    for (int l = 0; l < L; l++) virt_col[l] = l;
+    if (v.loc) {
+        // Half-row (j, h) lists its CPT local blocks first, then its share of the row's other blocks (the order of a row's slots is
+        // free: min1 / min2 / sign product are symmetric, a duplicated minimum gives min1 == min2); the column of local block cc is the
+        // thread group's virtual column (2j + h) + cc * 2J.
+        const int CPT = L / (2 * J), WCH = v.WC / 2;
+        std::vector<QcCnEdge> cn2(cn.size());
+        for (int j = 0; j < J; j++) {
+            std::vector<QcCnEdge> loc, oth;
+            for (int e = rowptr[j]; e < rowptr[j + 1]; e++) (owner[cn[e].col] == j ? loc : oth).push_back(cn[e]);
+            for (int h = 0; h < 2; h++) {
+                QcCnEdge *dst = &cn2[rowptr[j] + h * WCH];
+                for (int cc = 0; cc < CPT; cc++) {
+                    dst[cc] = loc[h * CPT + cc];
+                    virt_col[loc[h * CPT + cc].col] = (2 * j + h) + cc * 2 * J;
+                }
+                for (int i = CPT; i < WCH; i++) dst[i] = oth[h * (WCH - CPT) + (i - CPT)];
+            }
+        }
+        cn = cn2;
+    }
+    std::vector<QcVnEdge> vn((size_t)L * vnw, v.loc ? QcVnEdge{0xffff, 0} : QcVnEdge{0, 0});
     std::vector<int> fill(L, 0);
     for (int j = 0; j < J; j++) { // ascending REAL block row = the reference's edge order
         const int vj = virt_of[j];
         for (int e = rowptr[vj]; e < rowptr[vj + 1]; e++) {
             const int l = cn[e].col;
             // .e = padded block index (virtual row)*WC + position
-            if (!generic) vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(vj * v.WC + (e - rowptr[vj])), cn[e].shift};
+            if (v.loc) vn[(size_t)virt_col[l] * v.WV + j] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift}; // slot k = block row k
+            else if (!generic) vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(vj * v.WC + (e - rowptr[vj])), cn[e].shift};
         }
     }
     std::vector<unsigned char> wvb(L);
