@@ -148,6 +148,28 @@ template <int NF, int OFF> __device__ __forceinline__ void lds_st_imm(int base, 
         asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(base), "v"(v[0]), "n"(OFF) : "memory");
     }
 }
+// The same accesses on whole messages (float or v2f32), and the components of one.
+template <int NF> __device__ __forceinline__ typename Msg<NF>::T lds_ldm(int byte_off)
+{
+    typedef __attribute__((address_space(3))) const typename Msg<NF>::T lds_msg;
+    return *reinterpret_cast<lds_msg *>(static_cast<unsigned>(byte_off));
+}
+template <int NF, int OFF> __device__ __forceinline__ void lds_stm_imm(int base, typename Msg<NF>::T v)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_write has a 16-bit offset");
+    if constexpr (NF == 2) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(v), "n"(OFF) : "memory");
+    else asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(base), "v"(v), "n"(OFF) : "memory");
+}
+template <int NF> __device__ __forceinline__ float msg_get(const typename Msg<NF>::T &m, int v)
+{
+    if constexpr (NF == 2) return v ? m.y : m.x;
+    else return m;
+}
+template <int NF> __device__ __forceinline__ void msg_set(typename Msg<NF>::T &m, int v, float x)
+{
+    if constexpr (NF == 2) { if (v) m.y = x; else m.x = x; }
+    else m = x;
+}
 template <int... Is, typename Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f)
 {
     (f(std::integral_constant<int, Is>{}), ...);
