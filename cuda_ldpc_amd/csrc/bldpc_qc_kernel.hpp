@@ -115,8 +115,14 @@ template <int NF> __device__ __forceinline__ void lds_st(char *, int byte_off, c
 }
 
 // Compile-time geometry of one kernel variant: G*Z threads decode NF frames.
-template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int G_, int MINW_> struct QcGeom {
+// LOC: local edges as in QcGeom2 (see there): every column handed to one block row that contains it, L / J columns per row; the
+// variable of a local block lives in the check thread, its R and S never touch LDS.  Needs wave-uniform thread groups (Z whole
+// waves): the place of the local edge in its column's ascending order is a scalar per column.
+template <int NF_, int J_, int L_, int Z_, int WC_, int WV_, int G_, int MINW_, bool LOC_ = false> struct QcGeom {
     static constexpr int NF = NF_, J = J_, L = L_, Z = Z_, WC = WC_, WV = WV_, G = G_, MINW = MINW_;
+    static constexpr bool LOC = LOC_;
+    static constexpr int NLR = L / J; // LOC: local edges per row = its first NLR slots
+    static_assert(!LOC || (Z % 64 == 0 && L % J == 0 && L / J >= 1 && L / J <= WC_ && WV >= 2), "local edges: wave-uniform groups, L / J columns per row");
     static constexpr int RPT = (J + G - 1) / G, CPT = (L + G - 1) / G, TPB = G * Z;
     static constexpr int MSG = NF * 4;              // bytes per message slot
     static constexpr int Sslot = J * WC * Z;        // R blocks (row-padded to WC), then S columns
@@ -575,6 +581,11 @@ inline const QcVariant *qc_variants(int *count)
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::TPB,                            \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, false>, \
      k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>, "halfrow", 0, 0, 0, k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW>, true>},
+#define X1L(NF, J, L, Z, WC, WV, G, MINW)                                                                      \
+    {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>::TPB,                                \
+     QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, false>,  \
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, "row-local", 0, 0, 0,                                 \
+     k_qcp<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, 2},
 #define X2L(NF, J, L, Z, WC, WV, GJ, MINW)                                                                      \
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::TPB,                              \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, false>, \
@@ -595,6 +606,7 @@ inline const QcVariant *qc_variants(int *count)
         X2(2, 8, 24, 96, 10, 6, 4, 6) /* J8_L24_Z96: 768 thr, 80 KB, 2 WG/CU                                     */
         X2(2, 12, 24, 96, 8, 6, 4, 3) /* J12_L24_Z96 (rows padded 7 -> 8): 768 thr, 92 KB                        */
         X2(2, 6, 24, 96, 16, 4, 3, 3) /* J6_L24_Z96 (rows padded 15 -> 16): 576 thr, 92 KB                       */
+        X1L(2, 32, 64, 64, 7, 3, 16, 4) /* J32_L64_Z64 (BASELINE config 3) with local edges: every column of weight WV, the matching exists */
         QC_VARIANTS(X)
         /* check states in registers, S in LDS (bldpc_qcr_kernel.hpp), several workgroups per CU */
         XR(12, 69, 256, 256, 23, 22, 3) /* PON_LDPC J12_L69_Z256 (the reference's default, define.cuh:20-22): 69 KB, 2 WG/CU */
@@ -623,6 +635,7 @@ inline const QcVariant *qc_variants(int *count)
 #undef X
 #undef X2
 #undef X2L
+#undef X1L
 #undef XC
 #undef XR
 #undef XR2
@@ -680,7 +693,7 @@ inline void qc_plan_release(QcPlan *q)
 // row (CPT per half-row).  A bipartite matching with row capacities, by augmenting paths (J, L are tens).  owner[l] = row or -1.
 inline bool qc2_local_assign(int J, int L, const std::vector<unsigned short> &rowptr, const std::vector<QcCnEdge> &cn, std::vector<int> &owner)
 {
-    if (J <= 0 || L % (2 * J) != 0) return false;
+    if (J <= 0 || L % J != 0) return false;
     const int cap = L / J;
     std::vector<std::vector<int>> rows_of(L);
     for (int j = 0; j < J; j++)
@@ -774,7 +787,9 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         } else {
             if (v.J != J || v.L != L || v.Z != Z || v.WC < Wc || v.WV < Wv) continue;
             if ((size_t)v.lds_bytes > kLdsBytes) continue;
-            if (v.loc && (no_local || Wcmin != v.WC || !qc2_local_assign(J, L, rowptr, cn, owner))) continue; // every row full, every column placed
+            if (v.loc == 1 && (no_local || Wcmin != v.WC || L % (2 * J) != 0 || !qc2_local_assign(J, L, rowptr, cn, owner))) continue; // every row full, every column placed
+            if (v.loc == 2 && (no_local || Z % 64 != 0 || *std::min_element(wv.begin(), wv.end()) != v.WV || Wcmin < L / J ||
+                               !qc2_local_assign(J, L, rowptr, cn, owner))) continue; // every column full, every column placed
             q->lds_bytes = v.lds_bytes;
         }
         q->variant = vi;
@@ -871,7 +886,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     // reference's, ascending real block row: only the slot a block's messages live in changes.
     std::vector<int> virt_of(J);
     for (int j = 0; j < J; j++) virt_of[j] = j;
-    if (!generic && std::string(v.tag) == "row" && Z % 64 == 0 && J / v.G >= 2) {
+    if (!generic && std::string(v.tag).compare(0, 3, "row") == 0 && Z % 64 == 0 && J / v.G >= 2) {
         const int G = v.G, RPT = J / G;
         std::vector<int> order(J);
         for (int j = 0; j < J; j++) order[j] = j;
@@ -891,7 +906,23 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     }
     std::vector<int> virt_col(L);
     for (int l = 0; l < L; l++) virt_col[l] = l;
-    if (v.loc) {
+    if (v.loc == 2) {
+        // Row kernel: virtual row vj = g + rr*G lists its NLR local blocks first (the order of a row's slots is free); the column of
+        // local block i is the thread group's virtual column g + (rr*NLR + i)*G.
+        const int NLR = L / J, G = v.G;
+        std::vector<int> real_of(J);
+        for (int j = 0; j < J; j++) real_of[virt_of[j]] = j;
+        for (int vj = 0; vj < J; vj++) {
+            std::vector<QcCnEdge> loc, oth;
+            for (int e = rowptr[vj]; e < rowptr[vj + 1]; e++) (owner[cn[e].col] == real_of[vj] ? loc : oth).push_back(cn[e]);
+            for (int i = 0; i < NLR; i++) {
+                cn[rowptr[vj] + i] = loc[i];
+                virt_col[loc[i].col] = (vj % G) + ((vj / G) * NLR + i) * G;
+            }
+            for (size_t i = 0; i < oth.size(); i++) cn[rowptr[vj] + NLR + i] = oth[i];
+        }
+    }
+    if (v.loc == 1) {
         // Half-row (j, h) lists its CPT local blocks first, then its share of the row's other blocks (the order of a row's slots is
         // free: min1 / min2 / sign product are symmetric, a duplicated minimum gives min1 == min2); the column of local block cc is the
         // thread group's virtual column (2j + h) + cc * 2J.
@@ -911,19 +942,23 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         }
         cn = cn2;
     }
-    std::vector<QcVnEdge> vn((size_t)L * vnw, v.loc ? QcVnEdge{0xffff, 0} : QcVnEdge{0, 0});
-    std::vector<int> fill(L, 0);
+    std::vector<QcVnEdge> vn((size_t)L * vnw, v.loc == 1 ? QcVnEdge{0xffff, 0} : QcVnEdge{0, 0});
+    std::vector<int> fill(L, 0), fill_nl(L, 0), kloc(L, 0);
     for (int j = 0; j < J; j++) { // ascending REAL block row = the reference's edge order
         const int vj = virt_of[j];
         for (int e = rowptr[vj]; e < rowptr[vj + 1]; e++) {
             const int l = cn[e].col;
             // .e = padded block index (virtual row)*WC + position
-            if (v.loc) vn[(size_t)virt_col[l] * v.WV + j] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift}; // slot k = block row k
+            if (v.loc == 2) { // the column's other blocks in ascending real block row; kloc = where its local block stands among them
+                if (owner[l] == j) kloc[virt_col[l]] = fill[l];
+                else vn[(size_t)virt_col[l] * v.WV + fill_nl[l]++] = {(unsigned short)(vj * v.WC + (e - rowptr[vj])), cn[e].shift};
+                fill[l]++;
+            } else if (v.loc == 1) vn[(size_t)virt_col[l] * v.WV + j] = {(unsigned short)(j * v.WC + (e - rowptr[j])), cn[e].shift}; // slot k = block row k
             else if (!generic) vn[(size_t)l * v.WV + fill[l]++] = {(unsigned short)(vj * v.WC + (e - rowptr[vj])), cn[e].shift};
         }
     }
     std::vector<unsigned char> wvb(L);
-    for (int l = 0; l < L; l++) wvb[l] = (unsigned char)wv[l];
+    for (int l = 0; l < L; l++) wvb[l] = (unsigned char)(v.loc == 2 ? kloc[l] : wv[l]); // row kernel with local edges: per VIRTUAL column, the place of its local block
     CLDPC_HIP(hipMalloc((void **)&q->d_cn, cn.size() * sizeof(QcCnEdge)), BLDPC_ENOMEM);
     CLDPC_HIP(hipMalloc((void **)&q->d_rowptr, rowptr.size() * sizeof(unsigned short)), BLDPC_ENOMEM);
     CLDPC_HIP(hipMalloc((void **)&q->d_vn, vn.size() * sizeof(QcVnEdge)), BLDPC_ENOMEM);
