@@ -619,6 +619,71 @@ def test_other_lifting_sizes_random_matrices(C, orc, tmp_path, Z, J, L):
     assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
 
 
+def _write_blockh(path, H):
+    with open(path, "w") as f:
+        for row in H:
+            f.write("\t".join(str(int(x)) for x in row) + "\r\n")
+
+
+LOCAL_CASES = [  # (shape of, J, L, Z, how the pattern is made, tag expected in the kernel name)
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, "shifts", "halfrow-local"),    # the reference's block pattern, other shifts
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, "pattern", "halfrow-local"),   # full rows, other zero blocks: another matching, light columns
+    ("J4_L24_Z96_BlockH.txt", 4, 24, 96, "lightrow", "halfrow<"),       # a row of 19 blocks: no local edges, the plain half-row kernel
+    ("J32_L64_Z64_BlockH.txt", 32, 64, 64, "shifts", "row-local"),
+    ("J32_L64_Z64_BlockH.txt", 32, 64, 64, "permuted", "row-local"),    # block rows permuted: other row weights per thread group, other places of the local blocks
+    ("J32_L64_Z64_BlockH.txt", 32, 64, 64, "lightcol", "row<"),         # a column of weight 2: the plain row kernel
+]
+
+
+@pytest.mark.parametrize("fn,J,L,Z,how,tag", LOCAL_CASES)
+def test_local_edge_kernels_on_other_matrices(C, orc, tmp_path, monkeypatch, fn, J, L, Z, how, tag):
+    """k_qc / k_qc2 with local edges (one block per column stays in the check thread's registers, the column stored rotated): on
+    matrices other than the two the reference ships in these shapes -- other shifts, other block patterns (other matchings, other
+    places of the local block in its column's order, columns lighter than WV) -- the outputs equal the oracle's bit for bit
+    (hard bits, a-posteriori sums, flags; fixed, batch-global and per-frame exits) and those of the same code created under
+    BLDPC_NO_LOCAL=1; patterns the local-edge form does not take (a light row / a light column) fall back to the plain kernels."""
+    base = np.loadtxt(os.path.join(BL, fn), dtype=np.int64).reshape(J, L)
+    rng = np.random.default_rng(J * 1000 + len(how))
+    H = np.where(base >= 0, rng.integers(0, Z, size=(J, L)), -1)
+    if how == "pattern":  # four zero blocks per row at random, every column keeps at least two blocks
+        while True:
+            H = rng.integers(0, Z, size=(J, L))
+            for j in range(J):
+                H[j, rng.permutation(L)[:4]] = -1
+            if ((H >= 0).sum(0) >= 2).all() and ((H >= 0).sum(0) < J).any():
+                break
+    elif how == "lightrow":
+        H[1, int(np.argmax(H[1] >= 0))] = -1
+    elif how == "permuted":
+        H = H[rng.permutation(J)]
+    elif how == "lightcol":
+        H[int(np.argmax(H[:, 5] >= 0)), 5] = -1
+    path = str(tmp_path / "H.txt")
+    _write_blockh(path, H)
+    F = 5 if how in ("pattern", "permuted") else 6  # odd F: the regrouped input instead of the in-place read
+    snr = 3.0 if J == 4 else 0.5
+    y = _channel(orc, L * Z, F, snr)
+    ocode = orc.BinaryCode(path, J, L, Z)
+    code = C.BinaryCode.from_blockh(path, J, L, Z)
+    monkeypatch.setenv("BLDPC_NO_LOCAL", "1")
+    plain = C.BinaryCode.from_blockh(path, J, L, Z)
+    monkeypatch.delenv("BLDPC_NO_LOCAL")
+    for its in (1, 2, 7):
+        want = orc.bldpc_decode(ocode, y, F, its, early_exit=0, want_app=True)
+        got = _decode(C, code, y, F, max_iter=its, exit_mode=C.EXIT_FIXED, want_app=True)
+        assert tag in code.last_kernel, code.last_kernel
+        _assert_same(got, want, code.N, F)
+        ref = _decode(C, plain, y, F, max_iter=its, exit_mode=C.EXIT_FIXED, want_app=True)
+        assert "local" not in plain.last_kernel, plain.last_kernel
+        _assert_same(ref, want, code.N, F)
+    want = orc.bldpc_decode(ocode, y, F, 30, early_exit=1, want_app=True)
+    got = _decode(C, code, y, F, max_iter=30, exit_mode=C.EXIT_BATCH_GLOBAL, want_app=True, want_flag_hist=True)
+    _assert_same(got, want, code.N, F)
+    Dw, appw, itw = _oracle_per_frame(orc, ocode, y, F, 30)
+    D, app, it, _ = _decode_per_frame(C, code, y, F, 30, C.KERNEL_QC_LDS)
+    assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_long_block_kernels_on_random_shifts(C, orc, tmp_path, monkeypatch, seed):
     """J15_L30_Z1280's block pattern with RANDOM shifts: k_qcr2 (halo columns, tabulated wave-linear offsets, the wrapped blocks of a

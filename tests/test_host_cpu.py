@@ -203,6 +203,23 @@ def test_explicit_stack_walk_equals_the_recursion(tmp_path):
     assert out.startswith("OK "), out
 
 
+def test_local_edge_matching_is_valid(tmp_path):
+    """The fused row / half-row kernels keep one block per column out of LDS ("local edges"): the host hands every block column to
+    one block row containing it, L / J per row (qc2_local_assign, csrc/bldpc_qc_assign.hpp -- no HIP in that header).  On 1 400 random
+    block patterns that admit such an assignment it must find a valid one (also where single-block columns leave no choice), and
+    it must refuse rows lighter than their share and L not a multiple of J."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "qla")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "qc_local_assign_host_test.cpp")
+    subprocess.check_call([gxx, "-O2", "-std=c++17", src, "-o", exe], cwd=str(tmp_path))
+    out = subprocess.check_output([exe], timeout=120).decode()
+    assert out.startswith("OK 1400 "), out
+
+
 def test_qam_constellation_and_channel_equal_the_restatement(nbm, orc):
     """n_QAM != 2 branches (PARITY UNPINNED against the reference: its define.h fixes n_QAM = 2 and its tree holds no output of
     these branches): the library's reader and host channel equal the oracle's restatement of Get_CONSTELLATION / Modulate /
