@@ -55,6 +55,11 @@
 #define QC_PRIO_CN 0
 #define QC_PRIO_WR 1
 #endif
+// with local edges the output stage holds 7 stores and 20 of its 40 vector instructions feed no store: it stays at the arithmetic's
+// priority (12.59 -> 12.64 M codewords/s; 1 / 0 / 1 as above: 12.59; VN 2, CN 1, WR 0: 11.8; profiles/r03_qc2_variants.txt)
+#ifndef QC_PRIO_WR_LOC
+#define QC_PRIO_WR_LOC 0
+#endif
 
 namespace cldpc {
 
