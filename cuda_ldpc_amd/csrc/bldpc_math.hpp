@@ -68,9 +68,18 @@ template <int N, int STRIDE> __device__ __forceinline__ void cn_two_smallest(con
         m2 = __builtin_amdgcn_fmed3f(m1, m2, A(i));
         m1 = __builtin_fminf(m1, A(i));
     }
+    // the sign product two values at a time: v_bitop3_b32 (any 3-input bit function; 0x96 = a ^ b ^ c) issues at the full rate on
+    // gfx950, unlike v_or3 / v_and_or / v_bfi (tools/micro_rates.hip -> profiles/r03_micro_rates_bitop3.txt: 2.4 against 4.2 SIMD-cycles):
+    // 5 instructions instead of 10 for ten edges -- J4_L24_Z96 12.67 -> 13.03 M codewords/s, J32_L64_Z64 6.34 -> 6.53 M
+#ifdef QC_XOR2 /* experiment: one v_xor_b32 per value */
     sgn = 0u;
 #pragma unroll
     for (int k = 0; k < N; k++) sgn ^= f2u(q[k * STRIDE]);
+#else
+    sgn = (N % 2) ? f2u(q[0]) : (f2u(q[0]) ^ f2u(q[STRIDE]));
+#pragma unroll
+    for (int k = 2 - (N % 2); k + 1 < N; k += 2) sgn = __builtin_amdgcn_bitop3_b32(sgn, f2u(q[k * STRIDE]), f2u(q[(k + 1) * STRIDE]), 0x96);
+#endif
 }
 
 // R_i = Sign[25]*Sign[i] * (i == Index_minQ ? SubMinQ : MinQ)   (LDPC_Decoder.cu:298-312)

@@ -15,7 +15,7 @@ struct Stamp { unsigned long long c0, c1, r0, r1; };
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-enum { V_ADD, V_SUB, V_FMA, V_PK_ADD, V_PK_FMA, V_XOR, V_MIN, V_MAX, V_MED3, V_MED3_ABS, V_MIN_ABS, V_CNDMASK, V_DPP, V_LSHL_ADD, V_BFI, V_AND_OR, V_PERMLANE32, V_MIN3, V_MOV, V_NOPS, V_CNDMASK_S, V_AND, V_MAX3, V_CMP, V_SUB_NEG, V_XOR3, V_MIN_U32, V_MAX_U32, V_MIN_I32, V_SUB_U32, V_ADD_U32, V_ASHR, V_LSHR, V_BFE, V_PERM, V_MUL, V_OR, V_ADD3, V_MED3_U32, V_PK_MOV, V_MIN_U16, V_SUBREV, V_MAX_I32 };
+enum { V_ADD, V_SUB, V_FMA, V_PK_ADD, V_PK_FMA, V_XOR, V_MIN, V_MAX, V_MED3, V_MED3_ABS, V_MIN_ABS, V_CNDMASK, V_DPP, V_LSHL_ADD, V_BFI, V_AND_OR, V_PERMLANE32, V_MIN3, V_MOV, V_NOPS, V_CNDMASK_S, V_AND, V_MAX3, V_CMP, V_SUB_NEG, V_XOR3, V_MIN_U32, V_MAX_U32, V_MIN_I32, V_SUB_U32, V_ADD_U32, V_ASHR, V_LSHR, V_BFE, V_PERM, V_MUL, V_OR, V_ADD3, V_MED3_U32, V_PK_MOV, V_MIN_U16, V_SUBREV, V_MAX_I32, V_BITOP3, V_XOR_CHAIN, V_BITOP3_CHAIN };
 
 template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, Stamp *st, int iters, float seed)
 {
@@ -57,6 +57,9 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, Stam
                 if (OP == V_OR) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
                 if (OP == V_ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
                 if (OP == V_MED3_U32) asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+                if (OP == V_BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+                if (OP == V_XOR_CHAIN) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[0]) : "v"(u[(i + 1) & 7]));                                  // every instruction waits for the one before
+                if (OP == V_BITOP3_CHAIN) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(u[0]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
                 if (OP == V_PK_MOV) asm volatile("v_pk_mov_b32 %0, %1, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
                 if (OP == V_MIN_U16) asm volatile("v_min_u16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
                 if (OP == V_XOR3) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
@@ -291,7 +294,7 @@ int main()
         run_valu<V_MIN_U32>("v_min_u32", w); run_valu<V_MAX_U32>("v_max_u32", w); run_valu<V_MIN_I32>("v_min_i32", w); run_valu<V_MAX_I32>("v_max_i32", w);
         run_valu<V_SUB_U32>("v_sub_u32", w); run_valu<V_SUBREV>("v_subrev_u32", w); run_valu<V_ADD_U32>("v_add_u32", w); run_valu<V_ASHR>("v_ashrrev_i32", w);
         run_valu<V_LSHR>("v_lshrrev_b32", w); run_valu<V_BFE>("v_bfe_u32", w); run_valu<V_PERM>("v_perm_b32", w); run_valu<V_MUL>("v_mul_f32", w);
-        run_valu<V_OR>("v_or_b32", w); run_valu<V_ADD3>("v_add3_u32", w); run_valu<V_MED3_U32>("v_med3_u32", w); run_valu<V_PK_MOV>("v_pk_mov_b32", w);
+        run_valu<V_OR>("v_or_b32", w); run_valu<V_ADD3>("v_add3_u32", w); run_valu<V_MED3_U32>("v_med3_u32", w); run_valu<V_BITOP3>("v_bitop3_b32 (xor3)", w); run_valu<V_XOR_CHAIN>("v_xor_b32, dependent chain", w); run_valu<V_BITOP3_CHAIN>("v_bitop3_b32, dependent chain", w); run_valu<V_PK_MOV>("v_pk_mov_b32", w);
         run_valu<V_MIN_U16>("v_min_u16", w);
         printf("\n");
     }
