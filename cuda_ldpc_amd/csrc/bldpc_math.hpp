@@ -34,7 +34,7 @@ struct CnAcc {
     }
     // XOR key applied by out(): (min1 ^ min2) selects the other magnitude, the
     // top bit carries the row's sign product (Sign[25], LDPC_Decoder.cu:293-296).
-    __device__ __forceinline__ uint32_t key() const { return (f2u(m1) ^ f2u(m2)) ^ (sgn & 0x80000000u); }
+    __device__ __forceinline__ uint32_t key() const { return __builtin_amdgcn_bitop3_b32(f2u(m1), f2u(m2), sgn & 0x80000000u, 0x96); } // a ^ b ^ c in one full-rate instruction
 };
 
 // The two smallest magnitudes (with multiplicity) and the XOR of the sign bits of N values at once: what N calls of
