@@ -352,10 +352,11 @@ static int decode_impl(bldpc_code *c, const float *y, int F, int max_iter, int l
         CLDPC_HIP(c->bits.reserve((size_t)F * (c->N / 32) * sizeof(unsigned)), BLDPC_ENOMEM);
         CLDPC_HIP(c->yg.reserve(((size_t)F + 2) * c->N * sizeof(float)), BLDPC_ENOMEM);
         if (exit_mode == BLDPC_EXIT_BATCH_GLOBAL) CLDPC_HIP(c->itw.reserve((size_t)F * sizeof(int)), BLDPC_ENOMEM);
+        const char *used = c->qc.name;
         int r = qc_decode(&c->qc, y, F, max_iter, length, exit_mode, D, app, flag_hist, (unsigned long long *)c->bad.p,
                           (unsigned long long *)c->cnt.p, (unsigned *)c->bits.p, (float *)c->yg.p, itera, iters, (int *)c->itw.p, st,
-                          c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr, stat);
-        c->last_kernel = c->qc.name;
+                          c->profiling ? c->ev0 : nullptr, c->profiling ? c->ev1 : nullptr, stat, &used);
+        c->last_kernel = used;
         return r;
     }
     if (kernel != BLDPC_KERNEL_TABLE) return fail(BLDPC_EINVAL, "unknown kernel %d", kernel);

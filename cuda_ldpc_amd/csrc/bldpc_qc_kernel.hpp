@@ -588,13 +588,11 @@ inline const QcVariant *qc_variants(int *count)
 #define X1L(NF, J, L, Z, WC, WV, G, MINW)                                                                      \
     {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>::TPB,                                \
      QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, false>,  \
-     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, "row-local", 0, 0, 0,                                 \
-     k_qcp<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, 2},
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, "row-local", 0, 0, 0, nullptr, 2},
 #define X2L(NF, J, L, Z, WC, WV, GJ, MINW)                                                                      \
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::TPB,                              \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, false>, \
-     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, "halfrow-local", 0, 0, 0,                            \
-     k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, 1},
+     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, "halfrow-local", 0, 0, 0, nullptr, 1},
 #define XC(Z, U, G, CPT, WCS)                                                                              \
     {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
      k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, true, true>},
@@ -670,6 +668,10 @@ struct QcPlan {
     bool no_persist = false;    // BLDPC_NO_PERSIST: one workgroup per frame group even where the persistent form exists
     bool force_regroup = false; // BLDPC_REGROUP: k_regroup_y in front of the row / half-row kernels instead of reading in place
                                 // (BLDPC_NO_LOCAL, also read there: the half-row kernel without local edges)
+    // A plan with local edges carries the plain plan of the same code for the per-frame exit: frames leave after 3 ... 10 iterations
+    // there, a frame group's fixed cost counts, and the plain kernels' is lower (J4_L24_Z96 per-frame 44 / 59 / 66 against 40 / 53 /
+    // 59 M codewords/s at 3.0 / 3.6 / 4.2 dB, J32_L64_Z64 24.5 against 23.4 M; at 50 iterations the local edges win by 6-10 %)
+    QcPlan *pf = nullptr;
 };
 
 // bldpc_decode_statistic: per-frame error counts wanted from the pass that unpacks the hard bits (single-launch modes only).
@@ -691,11 +693,16 @@ inline void qc_plan_release(QcPlan *q)
     q->d_cn_meta = nullptr; q->d_vn_meta = nullptr;
     q->d_cn = nullptr; q->d_rowptr = nullptr; q->d_vn = nullptr; q->d_wv = nullptr;
     q->frames_per_wg = 0;
+    if (q->pf) {
+        qc_plan_release(q->pf);
+        delete q->pf;
+        q->pf = nullptr;
+    }
 }
 
 // Pick the first variant whose geometry matches the code, upload its block lists.  Leaves
 // frames_per_wg == 0 (not an error) when none does.  BLDPC_QC_VARIANT=<index> pins one (experiments).
-inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
+inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H, bool plain = false)
 {
     q->J = J; q->L = L; q->Z = Z;
     std::vector<QcCnEdge> cn;
@@ -723,7 +730,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
     const bool no_halo = getenv("BLDPC_NO_HALO") != nullptr; // tests: k_qcr on a code k_qcr2 takes
     q->no_persist = getenv("BLDPC_NO_PERSIST") != nullptr;
     q->force_regroup = getenv("BLDPC_REGROUP") != nullptr;
-    const bool no_local = getenv("BLDPC_NO_LOCAL") != nullptr;
+    const bool no_local = plain || getenv("BLDPC_NO_LOCAL") != nullptr;
     std::vector<int> owner; // half-row kernel with local edges: the block row every column is handed to
     // k_qcr2 gives per-lane addresses to two slots per (block row, tile): no more than two of a row's blocks may wrap past Z in
     // the same tile of 64 circulant positions (shifts taken relative to the register-resident column, as the kernel sees them)
@@ -951,6 +958,16 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H)
         q->persist_grid = std::max(8, ncu * std::max(1, occ) / 8 * 8);
     }
     q->frames_per_wg = v.NF;
+    if (v.loc && !plain) { // the per-frame exit's plan (see QcPlan::pf); without it the local-edge kernels serve that mode too
+        q->pf = new QcPlan();
+        const int rp = qc_plan_build(q->pf, J, L, Z, H, true);
+        if (rp || q->pf->frames_per_wg != v.NF || qc_variants(&nvar)[q->pf->variant].loc) {
+            qc_plan_release(q->pf);
+            delete q->pf;
+            q->pf = nullptr;
+            if (rp) return rp;
+        }
+    }
     snprintf(q->name, sizeof(q->name), "qc_lds_%s<nf%d,J%d,L%d,Z%d,wc%d,wv%d,g%d,w%d>t%d_lds%d", v.tag, v.NF, J, L, v.Z, v.WC, generic ? Wv : v.WV,
              v.G, v.MINW, v.threads, q->lds_bytes);
     return BLDPC_OK;
@@ -1020,8 +1037,10 @@ inline int qc_launch(const QcPlan *q, const float *y, int F, int max_iter, int l
 inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int length, int exit_mode, int *D, float *app,
                      unsigned long long *flag_hist, unsigned long long *hist_ws, unsigned long long *and_ws, unsigned *bits,
                      float *yg, int *itera, int *iters, int *iters_ws, hipStream_t st, hipEvent_t ev0 = nullptr,
-                     hipEvent_t ev1 = nullptr, QcStat *stat = nullptr)
+                     hipEvent_t ev1 = nullptr, QcStat *stat = nullptr, const char **used = nullptr)
 {
+    const QcPlan *qf = q->pf ? q->pf : q; // the plan of the per-frame passes
+    if (used) *used = (exit_mode == BLDPC_EXIT_PER_FRAME) ? qf->name : q->name;
     // k_qc / k_qc2 carry two frames per lane: with F even (and the frame-fastest rows 8-byte aligned) a lane's pair of channel
     // values is 8 contiguous bytes of the reference's own layout and the kernels read it in place -- every 64-byte sector is
     // shared by the 4 workgroups of 8 neighbouring frames, which the XCD-aware block order puts on one L2 -- instead of paying a
@@ -1038,7 +1057,7 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     }
     if (exit_mode == BLDPC_EXIT_PER_FRAME) { // every workgroup leaves when its own frames have stopped; nothing to wait for
         *itera = max_iter;
-        return qc_launch(q, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters, true, (int *)and_ws, stat, in_place);
+        return qc_launch(qf, y, F, max_iter, length, D, app, flag_hist ? flag_hist : hist_ws, bits, st, ev0, ev1, iters, true, (int *)and_ws, stat, in_place);
     }
     // Reference rule (LDPC_Decoder.cu:150-153): stop after the first iteration at which ALL frames are flagged.  No
     // workgroup can know that iteration while it runs, so it is found first and the batch then decoded with exactly that
@@ -1063,7 +1082,7 @@ inline int qc_decode(const QcPlan *q, const float *y, int F, int max_iter, int l
     int r;
     int run = max_iter;
     if (!q->ran_to_max) {
-        r = qc_launch(q, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false, (int *)and_ws, nullptr, in_place);
+        r = qc_launch(qf, y, F, max_iter, length, D, nullptr, hist, bits, st, nullptr, nullptr, iters_ws, /*expand=*/false, (int *)and_ws, nullptr, in_place);
         if (r) return r;
         int m = 0;
         CLDPC_HIP(hipMemsetAsync(and_ws, 0, sizeof(unsigned long long), st), BLDPC_EHIP);

@@ -14,6 +14,8 @@ import cuda_ldpc_amd as C  # noqa: E402
 CASES = [("J4_L24_Z96_BlockH.txt", 4, 24, 96, 4096, (3.0, 3.6, 4.2)), ("J4_L24_Z96_BlockH.txt", 4, 24, 96, 65536, (3.0, 3.6, 4.2)), ("J32_L64_Z64_BlockH.txt", 32, 64, 64, 65536, (0.0, -0.6)),
          ("J15_L30_Z1280_BlockH.txt", 15, 30, 1280, 8192, (0.0, -1.2)), ("PON_LDPC.txt", 12, 69, 256, 8192, (2.6,)),
          ("J10_L60_Z160_BlockH.txt", 10, 60, 160, 16384, (2.9, 3.2)), ("J4_L24_Z512_BlockH.txt", 4, 24, 512, 8192, (3.0,))]
+if os.environ.get("PFT_CASES"):  # experiments: a subset, e.g. PFT_CASES=1,2
+    CASES = [CASES[int(i)] for i in os.environ["PFT_CASES"].split(",")]
 for fn, J, L, Z, F, snrs in CASES:
     code = C.BinaryCode.from_blockh(os.path.join(ROOT, "data", "bldpc", fn), J, L, Z)
     for snr in snrs:
