@@ -78,9 +78,17 @@ __device__ __forceinline__ void qcr_iterations(const QcArgs &a, char *lds, int *
         // (inline asm: left to itself the compiler rebuilds a compare and a v_cndmask_b32 out of the C form)
         unsigned sel, mag, r;
         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(oh), "n"(p));               // all ones on the edge of the minimum
+#ifdef QCR_BFI /* experiment: the bit-field inserts as v_bfi_b32 (half rate) */
         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(mag) : "v"(sel), "v"(a2), "v"(a1));      // (m2 & sel) | (m1 & ~sel)
+#else
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(mag) : "v"(sel), "v"(a2), "v"(a1)); // (m2 & sel) | (m1 & ~sel), full rate
+#endif
         const unsigned sh = ww << (31 - (WCS - 1 - p));                                 // the edge's sign bit at bit 31
+#ifdef QCR_BFI
         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(0x80000000u), "v"(sh), "v"(mag)); // (sh & sign) | (mag & ~sign)
+#else
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(0x80000000u), "v"(sh), "v"(mag)); // (sh & sign) | (mag & ~sign)
+#endif
         return u2f(r);
     };
     // byte address of the S value behind row slot m for circulant position t: column base + (t + shift) mod Z
