@@ -70,7 +70,11 @@ __device__ __forceinline__ void qcr2_iterations(const QcArgs &a, char *lds, int 
     };
     auto recon = [&](float a1, float a2, unsigned ww, int p) -> float {
         const float mag = ((int)(ww >> 27) == p) ? a2 : a1;
+#ifdef QCR2_AND_OR /* experiment: the sign insert as the compiler's v_lshlrev + v_and_or_b32 (half rate) */
         return u2f(f2u(mag) | ((ww >> (WCS - 1 - p)) << 31));
+#else
+        return u2f(__builtin_amdgcn_bitop3_b32(ww << (31 - (WCS - 1 - p)), 0x80000000u, f2u(mag), 0xEA)); // (sh & sign) | mag: v_bitop3_b32 issues at the full rate
+#endif
     };
     auto flags_collect = [&](int it) { // two flag words, used by odd and even iterations in turn (see k_qc)
         if (tid == 0) {
