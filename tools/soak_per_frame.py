@@ -1,6 +1,6 @@
 """Soak of the early-exit paths at full batch size: (1) repeated per-frame decodes of the same batch give identical
 results (a race in the flag words or in the retire path would not), (2) fused kernels and table kernels agree frame by
-frame in per-frame mode, (3) batch-global agrees between the two kernel families.   usage: python tools/soak_per_frame.py"""
+frame in per-frame mode, (3) batch-global agrees between the two kernel families, (4) so do 50 fixed iterations, hard bits and a-posteriori sums.   usage: python tools/soak_per_frame.py"""
 import os
 import sys
 
@@ -38,9 +38,15 @@ for fn, J, L, Z, F, snrs in CASES:
         g2 = C.LDPC_Decoder_GPU(code, y, max_iter=50, exit_mode=C.EXIT_BATCH_GLOBAL, kernel=C.KERNEL_TABLE)
         torch.cuda.synchronize()
         same_g = g1["iteraTime"] == g2["iteraTime"] and torch.equal(g1["D"], g2["D"])
-        bad += (not same) + (not same_g)
+        # (4) fixed iterations at full batch size: the kernels bench.py times (local edges where the code has them), a-posteriori sums included
+        f1 = C.LDPC_Decoder_GPU(code, y, max_iter=50, exit_mode=C.EXIT_FIXED, kernel=C.KERNEL_QC_LDS, want_app=True)
+        kfixed = code.last_kernel
+        f2 = C.LDPC_Decoder_GPU(code, y, max_iter=50, exit_mode=C.EXIT_FIXED, kernel=C.KERNEL_TABLE, want_app=True)
+        torch.cuda.synchronize()
+        same_f = torch.equal(f1["D"], f2["D"]) and torch.equal(f1["app"].view(torch.int32), f2["app"].view(torch.int32))
+        bad += (not same) + (not same_g) + (not same_f)
         it = ref[1].float()
-        print("%-26s Es/N0 %5.1f F=%d: per-frame fused==table %s (mean %.2f it, max %d), batch-global fused==table %s (stops at %d) [%s]"
-              % (fn, snr, F, same, it.mean().item(), int(ref[1].max()), same_g, g1["iteraTime"], kname), flush=True)
+        print("%-26s Es/N0 %5.1f F=%d: per-frame fused==table %s (mean %.2f it, max %d), batch-global fused==table %s (stops at %d) [%s]; fixed 50 fused==table (bits and sums) %s [%s]"
+              % (fn, snr, F, same, it.mean().item(), int(ref[1].max()), same_g, g1["iteraTime"], kname, same_f, kfixed), flush=True)
 print("soak:", "OK" if bad == 0 else "%d MISMATCHES" % bad)
 sys.exit(1 if bad else 0)
