@@ -186,6 +186,30 @@ template <int... Is, typename Fn> __device__ __forceinline__ void static_for_imp
 }
 template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// Row kernel with local edges: the places (0 .. WV-1) of a thread group's CPT local blocks in their columns' orders, as one number
+// (digit cc = column cc, base WV).  The host sorts a row's local blocks by place and the rows of a group by their digit tuples, so only
+// the sorted codes occur; the kernel has one iteration loop per such code (and row weight), chosen once per wave.
+template <int WV> constexpr int qc_kdigit(int code, int cc)
+{
+    for (int i = 0; i < cc; i++) code /= WV;
+    return code % WV;
+}
+template <int WV, int RPT, int NLR> constexpr bool qc_kcode_sorted(int code)
+{
+    for (int rr = 0; rr < RPT; rr++)
+        for (int pp = 0; pp + 1 < NLR; pp++)
+            if (qc_kdigit<WV>(code, rr * NLR + pp) > qc_kdigit<WV>(code, rr * NLR + pp + 1)) return false;
+    for (int rr = 0; rr + 1 < RPT; rr++) { // rows of the group in lexicographic order of their tuples
+        for (int pp = 0; pp < NLR; pp++) {
+            const int a = qc_kdigit<WV>(code, rr * NLR + pp), b = qc_kdigit<WV>(code, (rr + 1) * NLR + pp);
+            if (a < b) break;
+            if (a > b) return false;
+        }
+    }
+    return true;
+}
+constexpr int qc_ipow(int b, int e) { return e == 0 ? 1 : b * qc_ipow(b, e - 1); }
+
 #define QC1_NAME k_qc
 #define QC1_PERSIST 0
 #include "bldpc_qc1_body.inc"
@@ -871,6 +895,12 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H, bool plai
         std::vector<int> order(J);
         for (int j = 0; j < J; j++) order[j] = j;
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rowptr[x + 1] - rowptr[x] > rowptr[y + 1] - rowptr[y]; });
+        if (v.loc == 2) { // local edges: the rows of a thread group in lexicographic order of their local blocks' (sorted) places, see qc_kcode_sorted
+            auto place = [&](int l) { int o = 0; for (int j2 = 0; j2 < owner[l]; j2++) o += (H[j2 * L + l] != -1) ? 1 : 0; return o; };
+            auto tuple_of = [&](int j) { std::vector<int> t; for (int l = 0; l < L; l++) if (owner[l] == j) t.push_back(place(l)); std::sort(t.begin(), t.end()); return t; };
+            for (int k0 = 0; k0 + RPT <= J; k0 += RPT)
+                std::stable_sort(order.begin() + k0, order.begin() + k0 + RPT, [&](int x, int y) { return tuple_of(x) < tuple_of(y); });
+        }
         for (int k = 0; k < J; k++) virt_of[order[k]] = (k / RPT) + (k % RPT) * G;
         std::vector<int> real_of(J);
         for (int j = 0; j < J; j++) real_of[virt_of[j]] = j;
@@ -895,6 +925,8 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H, bool plai
         for (int vj = 0; vj < J; vj++) {
             std::vector<QcCnEdge> loc, oth;
             for (int e = rowptr[vj]; e < rowptr[vj + 1]; e++) (owner[cn[e].col] == real_of[vj] ? loc : oth).push_back(cn[e]);
+            auto place = [&](int l) { int o = 0; for (int j2 = 0; j2 < owner[l]; j2++) o += (H[j2 * L + l] != -1) ? 1 : 0; return o; };
+            std::stable_sort(loc.begin(), loc.end(), [&](const QcCnEdge &x, const QcCnEdge &y) { return place(x.col) < place(y.col); }); // by place in the column's order
             for (int i = 0; i < NLR; i++) {
                 cn[rowptr[vj] + i] = loc[i];
                 virt_col[loc[i].col] = (vj % G) + ((vj / G) * NLR + i) * G;
