@@ -612,11 +612,17 @@ inline const QcVariant *qc_variants(int *count)
 #define X1L(NF, J, L, Z, WC, WV, G, MINW)                                                                      \
     {NF, J, L, Z, WC, WV, G, MINW, QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>::TPB,                                \
      QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>::lds_bytes, k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, false>,  \
-     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, "row-local", 0, 0, 0, nullptr, 2},
+     k_qc<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>, "row-local", 0, 0, 0, QC1L_PF(NF, J, L, Z, WC, WV, G, MINW), 2},
+#ifdef QC_LOCAL_PER_FRAME_ROW /* experiment: the per-frame exit of the ROW kernel on its local-edge form too (persistent form instantiated) */
+#define QC1L_PF(NF, J, L, Z, WC, WV, G, MINW) k_qcp<QcGeom<NF, J, L, Z, WC, WV, G, MINW, true>, true>
+#else
+#define QC1L_PF(NF, J, L, Z, WC, WV, G, MINW) nullptr
+#endif
 #define X2L(NF, J, L, Z, WC, WV, GJ, MINW)                                                                      \
     {NF, J, L, Z, WC, WV, GJ, MINW, QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::TPB,                              \
      QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>::lds_bytes, k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, false>, \
-     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, "halfrow-local", 0, 0, 0, nullptr, 1},
+     k_qc2<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, "halfrow-local", 0, 0, 0,                            \
+     k_qc2p<QcGeom2<NF, J, L, Z, WC, WV, GJ, MINW, true>, true>, 1},
 #define XC(Z, U, G, CPT, WCS)                                                                              \
     {1, 0, 0, Z, WCS, 31, G, 0, QccGeom<Z, U, G, CPT, WCS>::TPB, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, false>,   \
      k_qcc<QccGeom<Z, U, G, CPT, WCS>, true>, "compressed", U, CPT, 0, k_qcc<QccGeom<Z, U, G, CPT, WCS>, true, true>},
@@ -692,9 +698,11 @@ struct QcPlan {
     bool no_persist = false;    // BLDPC_NO_PERSIST: one workgroup per frame group even where the persistent form exists
     bool force_regroup = false; // BLDPC_REGROUP: k_regroup_y in front of the row / half-row kernels instead of reading in place
                                 // (BLDPC_NO_LOCAL, also read there: the half-row kernel without local edges)
-    // A plan with local edges carries the plain plan of the same code for the per-frame exit: frames leave after 3 ... 10 iterations
-    // there, a frame group's fixed cost counts, and the plain kernels' is lower (J4_L24_Z96 per-frame 44 / 59 / 66 against 40 / 53 /
-    // 59 M codewords/s at 3.0 / 3.6 / 4.2 dB, J32_L64_Z64 24.5 against 23.4 M; at 50 iterations the local edges win by 6-10 %)
+    // A ROW-kernel plan with local edges carries the plain plan of the same code for the per-frame exit: its flag-tracking
+    // instantiation keeps the branching variable-node phase (one loop per place code would be 210 KB there) and the plain kernel is the
+    // faster one for frames that leave after 3 ... 10 iterations (J32_L64_Z64 per-frame 24.5 against 23.4 M codewords/s).  The HALF-ROW
+    // kernel serves the per-frame exit with its local-edge form (persistent, k_qc2p<LOC>): 49 / 66 / 71 M against 44 / 59 / 66 M
+    // codewords/s at 3.0 / 3.6 / 4.2 dB (it was the other way round, 40 / 53 / 59 M, before the block-row choice left the loop).
     QcPlan *pf = nullptr;
 };
 
@@ -990,7 +998,7 @@ inline int qc_plan_build(QcPlan *q, int J, int L, int Z, const int *H, bool plai
         q->persist_grid = std::max(8, ncu * std::max(1, occ) / 8 * 8);
     }
     q->frames_per_wg = v.NF;
-    if (v.loc && !plain) { // the per-frame exit's plan (see QcPlan::pf); without it the local-edge kernels serve that mode too
+    if (v.loc == 2 && !plain && !getenv("BLDPC_LOCAL_PER_FRAME")) { // the per-frame exit's plan of the ROW kernel (see QcPlan::pf); without it the local-edge kernels serve that mode too
         q->pf = new QcPlan();
         const int rp = qc_plan_build(q->pf, J, L, Z, H, true);
         if (rp || q->pf->frames_per_wg != v.NF || qc_variants(&nvar)[q->pf->variant].loc) {

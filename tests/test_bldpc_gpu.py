@@ -642,8 +642,8 @@ def test_local_edge_kernels_on_other_matrices(C, orc, tmp_path, monkeypatch, fn,
     places of the local block in its column's order, columns lighter than WV) -- the outputs equal the oracle's bit for bit
     (hard bits, a-posteriori sums, flags; fixed, batch-global and per-frame exits) and those of the same code created under
     BLDPC_NO_LOCAL=1; patterns the local-edge form does not take (a light row / a light column) fall back to the plain kernels.  The
-    batch-global rule's full runs (flag history on) use the local-edge kernels, its per-frame pre-pass and the per-frame exit the plain
-    plan the code object carries beside them."""
+    batch-global rule's full runs (flag history on) use the local-edge kernels; the per-frame passes too on the half-row kernel, while
+    the row kernel runs them on the plain plan the code object carries beside the local-edge one."""
     base = np.loadtxt(os.path.join(BL, fn), dtype=np.int64).reshape(J, L)
     rng = np.random.default_rng(J * 1000 + len(how))
     H = np.where(base >= 0, rng.integers(0, Z, size=(J, L)), -1)
@@ -684,7 +684,9 @@ def test_local_edge_kernels_on_other_matrices(C, orc, tmp_path, monkeypatch, fn,
     Dw, appw, itw = _oracle_per_frame(orc, ocode, y, F, 30)
     D, app, it, _ = _decode_per_frame(C, code, y, F, 30, C.KERNEL_QC_LDS)
     assert np.array_equal(it, itw) and np.array_equal(D, Dw) and np.array_equal(app.view(np.uint32), appw.view(np.uint32))
-    assert "qc_lds" in code.last_kernel and "local" not in code.last_kernel  # the per-frame exit runs the plain plan of the same code (QcPlan::pf)
+    # the per-frame exit: the half-row kernel keeps its local-edge form (persistent for large batches), the row kernel runs the plain
+    # plan the code object carries beside the local-edge one (QcPlan::pf)
+    assert "qc_lds" in code.last_kernel and ("local" in code.last_kernel) == (tag == "halfrow-local")
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
